@@ -1,0 +1,207 @@
+"""Generate the golden vectors under ``tests/golden/`` by running the REFERENCE's own
+functions on seeded inputs (TEST INFRASTRUCTURE ONLY; run in the authoring container, where
+the read-only reference checkout is mounted — it does not exist on the GPU box).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [/root/reference]
+
+What is imported from the reference: ``modules.models`` (ExtendedFILIP static methods),
+``modules.training_utils_filip`` and ``modules.training_utils``.  The last one imports the
+third-party ``grad_cache`` package, which is not vendored and not installable offline; a
+pass-through stand-in for its two decorators (list arguments concatenated on dim 0 /
+identity) is registered first.  That stand-in is ours and contributes no arithmetic.
+
+Only inputs and outputs are stored (``.npz``, float32/uint8/int64 arrays): no reference
+source text goes into the repository.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _install_grad_cache_stand_in():
+    def cat_input_tensor(fn):
+        def wrapped(*args, **kw):
+            args = [torch.cat(list(a), dim=0) if isinstance(a, (list, tuple)) else a for a in args]
+            return fn(*args, **kw)
+        return wrapped
+
+    def cached(fn):
+        return fn
+
+    pkg = types.ModuleType("grad_cache")
+    sub = types.ModuleType("grad_cache.functional")
+    sub.cat_input_tensor = cat_input_tensor
+    sub.cached = cached
+    pkg.functional = sub
+    sys.modules["grad_cache"] = pkg
+    sys.modules["grad_cache.functional"] = sub
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def gen_clip(tu):
+    cases = {}
+    for seed, (B, d), t0, peaked in [
+        (0, (4, 8), 1.0, False),
+        (1, (16, 128), 0.0, False),
+        (2, (32, 128), 2.0, False),
+        (3, (32, 128), 1.0, True),
+        (4, (37, 128), 1.0, False),      # ragged batch (not a multiple of any tile)
+        (5, (64, 96), 0.5, False),       # d not a power of two
+    ]:
+        g = torch.Generator().manual_seed(seed)
+        e_pep = torch.randn(B, d, generator=g)
+        e_rec = e_pep + 0.1 * torch.randn(B, d, generator=g) if peaked else torch.randn(B, d, generator=g)
+        ep = e_pep.clone().requires_grad_(True)
+        er = e_rec.clone().requires_grad_(True)
+        t = torch.tensor(t0, requires_grad=True)
+        # modules/models.py:50-51 are two torch calls inside Encoder.forward (which needs
+        # the ESM trunk); they are issued here verbatim on the head output.
+        x = F.normalize(ep, dim=-1) * torch.exp(t / 2)
+        y = F.normalize(er, dim=-1) * torch.exp(t / 2)
+        loss = tu._contrastive_loss(x, y.t())
+        loss.backward()
+        xs2 = list(torch.chunk(x.detach(), 2, 0)); ys2 = list(torch.chunk(y.detach(), 2, 0))
+        xs4 = list(torch.chunk(x.detach(), 4, 0)); ys4 = list(torch.chunk(y.detach(), 4, 0))
+        key = f"s{seed}_B{B}_d{d}"
+        cases[key] = dict(
+            e_pep=_np(e_pep), e_rec=_np(e_rec), t=np.float32(t0),
+            x=_np(x), y=_np(y), loss=_np(loss), logits=_np(x.detach() @ y.detach().t()),
+            exp_logits=_np(tu.get_logits(xs2, ys2)),
+            loss_gc2=_np(tu._contrastive_loss_gc(xs2, ys2)),
+            loss_gc4=_np(tu._contrastive_loss_gc(xs4, ys4)),
+            d_e_pep=_np(ep.grad), d_e_rec=_np(er.grad), d_t=_np(t.grad),
+        )
+    flat = {f"{k}/{f}": v for k, c in cases.items() for f, v in c.items()}
+    np.savez_compressed(os.path.join(OUT, "clip_small.npz"), **flat)
+
+    # loss-only scalars at the benchmark sizes (inputs are regenerated from the seed)
+    scal = {}
+    for B in (256, 1024):
+        g = torch.Generator().manual_seed(0)
+        e_pep = torch.randn(B, 128, generator=g)
+        e_rec = torch.randn(B, 128, generator=g)
+        t = torch.tensor(1.0)
+        x = F.normalize(e_pep, dim=-1) * torch.exp(t / 2)
+        y = F.normalize(e_rec, dim=-1) * torch.exp(t / 2)
+        scal[f"loss_B{B}"] = _np(tu._contrastive_loss(x, y.t()))
+        e_rec2 = e_pep + 0.5 * torch.randn(B, 128, generator=g)
+        y2 = F.normalize(e_rec2, dim=-1) * torch.exp(t / 2)
+        scal[f"loss_peaked_B{B}"] = _np(tu._contrastive_loss(x, y2.t()))
+    np.savez_compressed(os.path.join(OUT, "clip_scalars.npz"), **scal)
+
+
+def _filip_inputs(seed, B, TA, TB, d, full=False, lo=3):
+    g = torch.Generator().manual_seed(seed)
+    hA = torch.randn(B, TA, d, generator=g)
+    hB = torch.randn(B, TB, d, generator=g)
+    if full:
+        lA = torch.full((B,), TA); lB = torch.full((B,), TB)
+    else:
+        lA = torch.randint(min(lo, TA), TA + 1, (B,), generator=g)
+        lB = torch.randint(min(lo, TB), TB + 1, (B,), generator=g)
+    mA = (torch.arange(TA)[None] < lA[:, None]).long()
+    mB = (torch.arange(TB)[None] < lB[:, None]).long()
+    return hA, hB, mA, mB
+
+
+def gen_filip(models, tuf):
+    FIL = models.ExtendedFILIP
+    cases = {}
+    for seed, (B, TA, TB, d), t0, kind in [
+        (0, (3, 5, 7, 8), 1.0, "raw"),
+        (1, (6, 9, 11, 16), 0.7, "raw"),
+        (2, (8, 48, 40, 128), 1.0, "raw"),
+        (3, (8, 48, 40, 128), 0.7, "bf16n"),   # operands already normalised and bf16-exact
+        (4, (5, 70, 33, 128), 1.3, "bf16n"),
+        (5, (4, 64, 64, 128), 1.0, "full"),    # no padding at all
+        (6, (6, 37, 29, 64), 1.0, "holes"),    # masks with interior holes (not right-padded)
+    ]:
+        hA, hB, mA, mB = _filip_inputs(seed, B, TA, TB, d, full=(kind == "full"))
+        if kind == "holes":
+            g = torch.Generator().manual_seed(100 + seed)
+            mA = (torch.rand(B, TA, generator=g) > 0.3).long(); mA[:, 0] = 1
+            mB = (torch.rand(B, TB, generator=g) > 0.3).long(); mB[:, 0] = 1
+        key = f"s{seed}_B{B}_TA{TA}_TB{TB}_d{d}_{kind}"
+        t = torch.tensor(t0, requires_grad=True)
+        if kind == "bf16n":
+            # pre-normalised, bf16-representable operands fed straight to the score function
+            nA = (hA / hA.norm(dim=-1, keepdim=True)).to(torch.bfloat16).float()
+            nB = (hB / hB.norm(dim=-1, keepdim=True)).to(torch.bfloat16).float()
+            a = nA.clone().requires_grad_(True); b = nB.clone().requires_grad_(True)
+            sA, sB = FIL._filip_similarity_score(a, b, mA, mB, t)
+            store_A, store_B = nA, nB
+        else:
+            a = hA.clone().requires_grad_(True); b = hB.clone().requires_grad_(True)
+            # modules/models.py:238-239 (two lines of ExtendedFILIP.forward, which needs the trunk)
+            na = a / a.norm(dim=-1, keepdim=True)
+            nb = b / b.norm(dim=-1, keepdim=True)
+            sA, sB = FIL._filip_similarity_score(na, nb, mA, mB, t)
+            store_A, store_B = hA, hB
+        loss = tuf._compute_loss(sA, sB)
+        loss.backward()
+        cases[key] = dict(
+            hA=_np(store_A), hB=_np(store_B), maskA=_np(mA).astype(np.uint8), maskB=_np(mB).astype(np.uint8),
+            t=np.float32(t0), sim_A=_np(sA), sim_B=_np(sB), loss=_np(loss),
+            loss_A=_np(tuf._contrastive_loss(sA.detach())), loss_B_dcl=_np(tuf._contrastive_loss(sB.detach(), use_dcl=True)),
+            d_hA=_np(a.grad), d_hB=_np(b.grad), d_t=_np(t.grad),
+        )
+    flat = {f"{k}/{f}": v for k, c in cases.items() for f, v in c.items()}
+    np.savez_compressed(os.path.join(OUT, "filip_small.npz"), **flat)
+
+    # benchmark-size instance: B=256, L=256, d=128, bf16-rounded raw inputs, lengths in [128,256];
+    # the reference score function is run on 16x16 pair blocks (exact: a pair's scores depend
+    # on that pair alone).  Only sim_A/sim_B/loss are kept (inputs are regenerated from the seed).
+    B, L, d = 256, 256, 128
+    g = torch.Generator().manual_seed(0)
+    hA = torch.randn(B, L, d, generator=g).to(torch.bfloat16).float()
+    hB = torch.randn(B, L, d, generator=g).to(torch.bfloat16).float()
+    lA = torch.randint(128, 257, (B,), generator=g)
+    lB = torch.randint(128, 257, (B,), generator=g)
+    mA = (torch.arange(L)[None] < lA[:, None]).long()
+    mB = (torch.arange(L)[None] < lB[:, None]).long()
+    nA = hA / hA.norm(dim=-1, keepdim=True)
+    nB = hB / hB.norm(dim=-1, keepdim=True)
+    t = torch.tensor(1.0)
+    sA = torch.empty(B, B); sB = torch.empty(B, B)
+    blk = 16
+    with torch.no_grad():
+        for i0 in range(0, B, blk):
+            for j0 in range(0, B, blk):
+                a_, b_ = FIL._filip_similarity_score(nA[i0:i0+blk], nB[j0:j0+blk], mA[i0:i0+blk], mB[j0:j0+blk], t)
+                sA[i0:i0+blk, j0:j0+blk] = a_; sB[i0:i0+blk, j0:j0+blk] = b_
+            print("filip B256 block row", i0, flush=True)
+        loss = tuf._compute_loss(sA, sB)
+    np.savez_compressed(os.path.join(OUT, "filip_b256_l256.npz"), sim_A=_np(sA), sim_B=_np(sB), loss=_np(loss),
+                        lenA=_np(lA), lenB=_np(lB))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    sys.dont_write_bytecode = True
+    _install_grad_cache_stand_in()
+    sys.path.insert(0, REF)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    import modules.models as models
+    import modules.training_utils as tu
+    import modules.training_utils_filip as tuf
+    gen_clip(tu)
+    print("clip goldens written", flush=True)
+    gen_filip(models, tuf)
+    print("filip goldens written", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+"""Pins the CPU oracle (oracle/pclip_oracle.py) to the golden vectors produced by the
+reference's own functions (oracle/gen_golden.py).  CPU only."""
+import torch
+import pytest
+
+from oracle import pclip_oracle as O
+from conftest import load_flat
+
+
+def close(a, b, rtol, atol):
+    torch.testing.assert_close(a, b.to(a.dtype), rtol=rtol, atol=atol)
+
+
+def test_clip_small_cases(clip_cases):
+    assert len(clip_cases) == 6
+    for key, c in clip_cases.items():
+        t = c["t"]
+        x = O.l2norm_scale(c["e_pep"], t)
+        y = O.l2norm_scale(c["e_rec"], t)
+        close(x, c["x"], 1e-6, 1e-7)
+        close(y, c["y"], 1e-6, 1e-7)
+        close(O.clip_logits(x, y), c["logits"], 1e-5, 1e-6)
+        close(O.clip_contrastive_loss(x, y.t()), c["loss"], 1e-6, 1e-6)
+        xs = list(torch.chunk(x, 2)); ys = list(torch.chunk(y, 2))
+        close(O.clip_contrastive_loss_gc(xs, ys), c["loss_gc2"], 1e-6, 1e-6)
+        close(O.clip_contrastive_loss_gc(list(torch.chunk(x, 4)), list(torch.chunk(y, 4))), c["loss_gc4"], 1e-6, 1e-6)
+        close(O.clip_get_logits(xs, ys), c["exp_logits"], 1e-5, 1e-6)
+        # the reference's list variant equals its plain variant
+        close(c["loss_gc2"], c["loss"], 1e-6, 1e-6)
+        for step in (O.clip_step, O.clip_step_analytic):
+            loss, dp, dr, dt = step(c["e_pep"], c["e_rec"], t)
+            close(loss, c["loss"], 1e-6, 1e-6)
+            close(dp, c["d_e_pep"], 1e-4, 2e-7)
+            close(dr, c["d_e_rec"], 1e-4, 2e-7)
+            close(dt, c["d_t"], 1e-4, 1e-6)
+
+
+def test_clip_scalars_at_benchmark_sizes():
+    g = load_flat("clip_scalars.npz")
+    for B in (256, 1024):
+        gen = torch.Generator().manual_seed(0)
+        e_pep = torch.randn(B, 128, generator=gen)
+        e_rec = torch.randn(B, 128, generator=gen)
+        t = torch.tensor(1.0)
+        x = O.l2norm_scale(e_pep, t)
+        close(O.clip_contrastive_loss(x, O.l2norm_scale(e_rec, t).t()), g[f"loss_B{B}"], 1e-6, 1e-6)
+        e_rec2 = e_pep + 0.5 * torch.randn(B, 128, generator=gen)
+        close(O.clip_contrastive_loss(x, O.l2norm_scale(e_rec2, t).t()), g[f"loss_peaked_B{B}"], 1e-6, 1e-6)
+
+
+def test_clip_uniform_logits_give_log_B():
+    S = torch.zeros(16, 16)
+    close(O.clip_loss_from_logits(S), torch.log(torch.tensor(16.0)), 1e-6, 1e-6)
+
+
+def test_filip_small_cases(filip_cases):
+    assert len(filip_cases) == 7
+    for key, c in filip_cases.items():
+        t = c["t"]
+        pre = key.endswith("bf16n")
+        if pre:
+            sA, sB = O.filip_similarity(c["hA"], c["hB"], c["maskA"], c["maskB"], t, block=3)
+        else:
+            sA, sB = O.filip_similarity(O.filip_normalise(c["hA"]), O.filip_normalise(c["hB"]),
+                                        c["maskA"], c["maskB"], t, block=3)
+        close(sA, c["sim_A"], 1e-5, 1e-6)
+        close(sB, c["sim_B"], 1e-5, 1e-6)
+        close(O.filip_loss(sA, sB), c["loss"], 1e-5, 1e-6)
+        close(O.row_ce(c["sim_A"]), c["loss_A"], 1e-5, 1e-6)
+        close(O.row_ce(c["sim_B"], use_dcl=True), c["loss_B_dcl"], 1e-5, 1e-6)
+        if not pre:
+            loss, s1, s2, dA, dB, dt = O.filip_step(c["hA"], c["hB"], c["maskA"], c["maskB"], t, block=4)
+            close(loss, c["loss"], 1e-5, 1e-6)
+            close(dA, c["d_hA"], 1e-3, 1e-7)
+            close(dB, c["d_hB"], 1e-3, 1e-7)
+            close(dt, c["d_t"], 1e-4, 1e-6)
+
+
+def test_filip_block_decomposition_matches_one_shot(filip_cases):
+    c = filip_cases["s2_B8_TA48_TB40_d128_raw"]
+    nA, nB = O.filip_normalise(c["hA"]), O.filip_normalise(c["hB"])
+    a1, b1 = O.filip_similarity(nA, nB, c["maskA"], c["maskB"], c["t"], block=8)
+    a2, b2 = O.filip_similarity(nA, nB, c["maskA"], c["maskB"], c["t"], block=3)
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+
+
+def test_filip_benchmark_size_rows():
+    """A slice of the B=256, L=256 reference scores (rows 0..7) from regenerated inputs."""
+    g = load_flat("filip_b256_l256.npz")
+    B, L, d = 256, 256, 128
+    gen = torch.Generator().manual_seed(0)
+    hA = O.bf16_round(torch.randn(B, L, d, generator=gen))
+    hB = O.bf16_round(torch.randn(B, L, d, generator=gen))
+    lA = torch.randint(128, 257, (B,), generator=gen)
+    lB = torch.randint(128, 257, (B,), generator=gen)
+    assert torch.equal(lA, g["lenA"]) and torch.equal(lB, g["lenB"])
+    mA, mB = O.right_padded_masks(lA, L), O.right_padded_masks(lB, L)
+    sA, sB = O.filip_similarity(O.filip_normalise(hA[:8]), O.filip_normalise(hB[:32]), mA[:8], mB[:32],
+                                torch.tensor(1.0), block=8)
+    close(sA, g["sim_A"][:8, :32], 1e-5, 1e-6)
+    close(sB, g["sim_B"][:8, :32], 1e-5, 1e-6)
+    close(O.filip_loss(g["sim_A"], g["sim_B"]), g["loss"], 1e-6, 1e-6)

@@ -1,0 +1,167 @@
+/*
+ * pclip.h — C ABI of the MI355X (gfx950) contrastive hot path: L2-normalise, CLIP BxB
+ * logits + symmetric InfoNCE, FILIP token-wise max similarity + row InfoNCE, and the
+ * backward of each.
+ *
+ * The reference (pan-emily/protein-clip) is pure Python and has no FFI of its own: the
+ * "interface" each entry point replaces is the run of torch calls cited beside it
+ * (paths relative to the reference checkout).  The Python host side
+ * (protein-clip_amd/) binds these with ctypes and re-exports the reference's function
+ * names on top.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous row-major memory owned by the caller;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are
+ *    enqueued on it and the call returns without synchronising;
+ *  - nothing here allocates or frees device memory: scratch comes in through `ws`, sized
+ *    by the matching *_workspace_bytes() query (256-byte aligned base expected);
+ *  - return value 0 = enqueued; <0 = rejected before any launch, message from
+ *    pclip_last_error() (thread-local);
+ *  - scalars that live on the device in the reference (the learnable temperature, the
+ *    upstream gradient of the loss) are passed as device pointers so no call ever forces a
+ *    host sync.
+ */
+#ifndef PCLIP_H
+#define PCLIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCLIP_OK 0
+#define PCLIP_EINVAL (-1)   /* bad argument (null pointer, size out of the supported range) */
+#define PCLIP_ELAUNCH (-2)  /* the HIP runtime refused a launch */
+#define PCLIP_EDEVICE (-3)  /* not a gfx950 device / no device */
+
+/* limits of this build (checked, never silently exceeded) */
+#define PCLIP_CLIP_MAX_D 128     /* CLIP embedding width handled by the MFMA kernels      */
+#define PCLIP_FILIP_MAX_D 128    /* FILIP token embedding width (zero-padded to 128)      */
+#define PCLIP_FILIP_MAX_T 256    /* FILIP tokens per sequence handled by one LDS image    */
+
+int pclip_version(void);
+const char* pclip_last_error(void);
+/* 0 when device `dev` is a gfx950 part this library's code objects run on. */
+int pclip_check_device(int dev);
+
+/* ---------------------------------------------------------------------------------------
+ * Row L2-normalise + temperature scale.
+ * Replaces modules/models.py:50-51:  x = F.normalize(e, dim=-1) * exp(t / 2)
+ *   e [B,d] f32, t device scalar, x [B,d] f32.   Any B >= 1, 1 <= d <= 4096.
+ * ------------------------------------------------------------------------------------- */
+int pclip_l2norm_scale_fwd(const float* e, const float* t, float* x, int B, int d, void* stream);
+
+/* Backward of the above (autograd of models.py:50-51 under loss.backward(),
+ * modules/training_utils.py:71).  dx is given as `nslab` partial slabs of [B,d] f32, slab
+ * s at dx + s*slab_stride (elements), which are summed first (nslab = 1 for a plain dx).
+ *   de [B,d] f32 is overwritten;  dt (device scalar) is ACCUMULATED into: dt += dL/dt,
+ *   zero it first unless that is what you want (both towers add into one temperature).
+ *   g: optional device scalar multiplying dx (NULL = 1). */
+int pclip_l2norm_scale_bwd(const float* e, const float* t, const float* dx, int nslab, size_t slab_stride,
+                           const float* g, float* de, float* dt, int B, int d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * CLIP symmetric InfoNCE.
+ * Replaces modules/training_utils.py:85-89 (_contrastive_loss) and :260-264
+ * (_contrastive_loss_gc): S = X Y^T; loss = 0.5*(CE_rows(S) + CE_cols(S)) with the diagonal
+ * as target.  Computed with a max-shifted log-sum-exp (same value, no overflow).
+ *
+ * Sharded form: the caller owns rows [row_offset, row_offset+Br) of a global batch of Bg
+ * pairs.  X_own/Y_own [Br,d] are its rows, X_all/Y_all [Bg,d] the gathered batch (for one
+ * GPU: Br = Bg, row_offset = 0, *_own = *_all).
+ *   lse_row [Br]  log sum_j exp(S[i,j])  for the caller's rows i
+ *   lse_col [Br]  log sum_i exp(S[i,j])  for the caller's columns j
+ *   loss_part     device scalar: (0.5/Bg) * sum_{own i} (lse_row_i + lse_col_i - 2 S_ii)
+ *                 (= the loss itself on one GPU; summed over ranks otherwise)
+ *   logits_out    optional [Br,Bg] f32: S (mode 1) or exp(S) (mode 2, what
+ *                 get_logits returns, modules/training_utils.py:170-172); NULL/mode 0 = none
+ * d % 4 == 0, d <= PCLIP_CLIP_MAX_D.
+ * ------------------------------------------------------------------------------------- */
+size_t pclip_clip_workspace_bytes(int Br, int Bg, int d);
+int pclip_clip_fwd(const float* X_own, const float* Y_own, const float* X_all, const float* Y_all,
+                   int Br, int Bg, int d, int row_offset,
+                   float* lse_row, float* lse_col, float* loss_part,
+                   float* logits_out, int logits_mode, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward (autograd of the same lines): with G = (0.5/Bg)(softmax_rows(S) + softmax_cols(S) - 2I),
+ *   dX_own = g * G[own,:] Y_all,   dY_own = g * G[:,own]^T X_all.
+ *   lse_row_all / lse_col_all [Bg]: the gathered vectors from pclip_clip_fwd.
+ *   g: optional device scalar (upstream gradient of the loss; NULL = 1). */
+int pclip_clip_bwd(const float* X_own, const float* Y_own, const float* X_all, const float* Y_all,
+                   const float* lse_row_all, const float* lse_col_all,
+                   int Br, int Bg, int d, int row_offset, const float* g,
+                   float* dX_own, float* dY_own, void* ws, size_t ws_bytes, void* stream);
+
+/* One-GPU fused step from raw head outputs (models.py:50-51 on both towers, then
+ * training_utils.py:85-89, then loss.backward()): writes loss, d e_pep, d e_rec and dt
+ * (dt is overwritten here). */
+size_t pclip_clip_step_workspace_bytes(int B, int d);
+int pclip_clip_step(const float* e_pep, const float* e_rec, const float* t, int B, int d,
+                    float* loss, float* de_pep, float* de_rec, float* dt,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Row-wise InfoNCE with the diagonal as target.
+ * Replaces modules/training_utils_filip.py:15-23 (_contrastive_loss, incl. use_dcl).
+ *   logits [Br,Bc] f32; the target of row i is column i + row_offset.
+ *   lse [Br] out;  loss_part: device scalar (1/Bg) * sum_i (lse_i - logits[i, i+off]).
+ * Backward: dlogits[i,j] = g * (1/Bg) * (softmax_i(j) - [j == i+off])   (dcl: the diagonal is
+ * absent from the softmax).
+ * ------------------------------------------------------------------------------------- */
+int pclip_rowce_fwd(const float* logits, int Br, int Bc, int row_offset, int Bg, int use_dcl,
+                    float* lse, float* loss_part, void* stream);
+int pclip_rowce_bwd(const float* logits, const float* lse, int Br, int Bc, int row_offset, int Bg,
+                    int use_dcl, const float* g, float gscale, float* dlogits, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * FILIP token-wise similarity.
+ * Replaces modules/models.py:238-239 (token normalise, no epsilon) and :292-356
+ * (_filip_similarity_score): sim[i,j,a,b] = hA[i,a].hB[j,b] / t; padded pairs -> finfo.min;
+ * sim_A[i,j] = mean over valid a of max_b, sim_B[i,j] = mean over valid b of max_a.
+ * The contraction runs on bf16 matrix cores with f32 accumulation.
+ *
+ * Step 1, prep: h [B,T,d] f32 -> hn [B,Tp,128] bf16 (Tp = T rounded up to 32; pad rows and
+ * pad columns zero), optionally normalised per token and optionally negated (pass
+ * negate = 1 for the A side when t < 0, so that max(x/t) = max(-x)/|t|); maskw [B,Tp/32]
+ * u32 = the mask bits of each 32-token tile (bit r = token 32*tile + r; any nonzero mask
+ * byte counts as valid, as .bool() does at models.py:323-324).
+ * ------------------------------------------------------------------------------------- */
+int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, int normalise, int negate,
+                     uint16_t* hn, uint32_t* maskw, void* stream);
+
+/* Step 2, scores.  hnA [Br,TAp,128], hnB [Bc,TBp,128] bf16 from prep; inv_abs_t = 1/|t| as a
+ * device scalar pointer `t` (the kernel reads t and uses 1/|t|).
+ *   sim_A, sim_B [Br,Bc] f32
+ *   argA [Br,Bc,TAp] u16: for each a the b attaining the max (0 where a is padding)
+ *   argB [Br,Bc,TBp] u16: for each b the a attaining the max
+ * (argA/argB feed the backward; pass NULL for both to skip them in inference.)
+ * TA, TB <= PCLIP_FILIP_MAX_T. */
+int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
+                        const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,
+                        const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
+                        void* stream);
+
+/* Step 3, backward of the scores w.r.t. the bf16 operands (autograd of models.py:332-351:
+ * the max routes each gradient to its arg-max partner).  gA, gB [Br,Bc] f32 = d loss / d sim_A,
+ * d loss / d sim_B.  Outputs (f32, OVERWRITTEN): dnA [Br,TA,128p] and dnB [Bc,TB,128p] hold
+ * d loss / d (normalised operand) in the padded [.,Tp,128] layout of prep; dt is
+ * ACCUMULATED: dt += -(1/t) * sum(gA*sim_A + gB*sim_B). */
+int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
+                        const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,
+                        const float* t, const float* sim_A, const float* sim_B,
+                        const uint16_t* argA, const uint16_t* argB,
+                        const float* gA, const float* gB,
+                        float* dnA, float* dnB, float* dt, void* stream);
+
+/* Step 4, backward of prep: dn [B,Tp,128] f32 (padded layout) -> dh [B,T,d] f32 through the
+ * normalise Jacobian (I - n n^T)/|h| when normalise = 1 (identity otherwise), sign flipped
+ * when negate = 1.  When `accumulate` is nonzero dh += instead of dh =. */
+int pclip_filip_prep_bwd(const float* h, const float* dn, int B, int T, int d, int normalise, int negate,
+                         int accumulate, float* dh, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCLIP_H */

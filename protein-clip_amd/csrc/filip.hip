@@ -1,0 +1,428 @@
+// FILIP token-wise max similarity on bf16 matrix cores (v_mfma_f32_32x32x16_bf16), gfx950.
+//
+// Layout in HBM: each sequence is a [Tp][128] bf16 image (Tp = tokens rounded up to 32,
+// width zero-padded to 128; padding rows and masked tokens are zero) plus one u32 of mask
+// bits per 32-token tile.  The [B,B,TA,TB] similarity tensor of the reference is never
+// formed: a workgroup owns one A sequence (its tiles live in registers as MFMA A operands),
+// streams B sequences through an XOR-swizzled LDS image, and reduces each 32x32 tile to a
+// running row maximum (elementwise, reduced across lanes once per pair) and a column
+// maximum (over registers) as soon as the tile leaves the matrix core.
+#include "pclip_common.h"
+
+#define FD 128            // padded embedding width
+#define ROWB (FD * 2)     // bytes per token row
+
+// ---- prep: f32 [B,T,d] -> bf16 [B,Tp,128] (+ mask words) --------------------------------
+// One block per 32-token tile of one sequence; wave w converts tokens w, w+4, ...
+__global__ __launch_bounds__(256) void filip_prep_kernel(const float* __restrict__ h, const uint8_t* __restrict__ mask, int B, int T, int d,
+                                                         int Tp, int normalise, int negate, uint16_t* __restrict__ hn,
+                                                         uint32_t* __restrict__ maskw) {
+    const int ntile = Tp >> 5;
+    const int seq = blockIdx.x / ntile, tile = blockIdx.x - seq * ntile;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (w == 0) {
+        const int tok = tile * 32 + (lane & 31);
+        const bool on = lane < 32 && tok < T && mask[(size_t)seq * T + tok] != 0;
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) maskw[(size_t)seq * ntile + tile] = (uint32_t)bal;
+    }
+    for (int r = w; r < 32; r += 4) {
+        const int tok = tile * 32 + r;
+        const bool live = tok < T && mask[(size_t)seq * T + tok] != 0;
+        float v0 = 0.f, v1 = 0.f;
+        if (live) {
+            const float* hr = h + ((size_t)seq * T + tok) * d;
+            const int k = 2 * lane;
+            if (k < d) v0 = hr[k];
+            if (k + 1 < d) v1 = hr[k + 1];
+            if (normalise) {
+                const float ss = wave_sum(v0 * v0 + v1 * v1);
+                const float nrm = sqrtf(ss);
+                v0 = v0 / nrm;
+                v1 = v1 / nrm;
+            }
+            if (negate) {
+                v0 = -v0;
+                v1 = -v1;
+            }
+        }
+        const __bf16 b0 = (__bf16)v0, b1 = (__bf16)v1;
+        const uint32_t packed = (uint32_t)__builtin_bit_cast(uint16_t, b0) | ((uint32_t)__builtin_bit_cast(uint16_t, b1) << 16);
+        reinterpret_cast<uint32_t*>(hn + ((size_t)seq * Tp + tok) * FD)[lane] = packed;
+    }
+}
+
+// ---- prep backward: dn [B,Tp,128] f32 -> dh [B,T,d] f32 --------------------------------
+// Masked and padding tokens carry a zero dn (the score backward never touches them), so
+// their dh comes out zero without consulting the mask.
+__global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dn, int B, int T, int d,
+                                                             int Tp, int normalise, int negate, int accumulate, float* __restrict__ dh) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (size_t)B * T) return;
+    const int seq = (int)(row / T), tok = (int)(row - (size_t)seq * T);
+    const float* hr = h + row * d;
+    const float* gr = dn + ((size_t)seq * Tp + tok) * FD;
+    float* out = dh + row * d;
+    const int k = 2 * lane;
+    float g0 = 0.f, g1 = 0.f, v0 = 0.f, v1 = 0.f;
+    if (k < d) { g0 = gr[k]; v0 = hr[k]; }
+    if (k + 1 < d) { g1 = gr[k + 1]; v1 = hr[k + 1]; }
+    const float sgn = negate ? -1.f : 1.f;
+    float o0 = g0 * sgn, o1 = g1 * sgn;
+    if (normalise) {
+        const float ss = wave_sum(v0 * v0 + v1 * v1);
+        const float dot = wave_sum(v0 * g0 + v1 * g1);
+        if (ss > 0.f) {
+            const float inv = 1.f / sqrtf(ss);
+            const float ndg = dot * inv * inv;  // (h.g)/|h|^2
+            o0 = (g0 - v0 * ndg) * inv * sgn;
+            o1 = (g1 - v1 * ndg) * inv * sgn;
+        }
+    }
+    if (k < d) out[k] = accumulate ? out[k] + o0 : o0;
+    if (k + 1 < d) out[k + 1] = accumulate ? out[k + 1] + o1 : o1;
+}
+
+// ---- scores ------------------------------------------------------------------------------
+struct FilipArgs {
+    const uint16_t* hnA; const uint32_t* mwA; int Br, TAp;
+    const uint16_t* hnB; const uint32_t* mwB; int Bc, TBp;
+    const float* t;
+    float* simA; float* simB;
+    uint16_t* argA; uint16_t* argB;
+    int jchunk;  // B sequences per workgroup
+};
+
+// LDS: B image [TBp][256 B] swizzled | colpart float2 [4][256] | rsum float[4] | red float[4]
+#define LDS_IMG 0
+#define LDS_COLPART (256 * ROWB)
+#define LDS_RSUM (LDS_COLPART + 4 * 256 * 8)
+#define LDS_RED (LDS_RSUM + 16)
+#define LDS_TOTAL (LDS_RED + 32)
+
+__global__ __launch_bounds__(256, 2) void filip_sim_kernel(FilipArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* colpart = reinterpret_cast<float2*>(smem + LDS_COLPART);
+    float* rsum = reinterpret_cast<float*>(smem + LDS_RSUM);
+    float* red = reinterpret_cast<float*>(smem + LDS_RED);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int i = blockIdx.x % p.Br;
+    const int chunk = blockIdx.x / p.Br;
+    const int j_begin = chunk * p.jchunk, j_end = min(p.Bc, j_begin + p.jchunk);
+    const int ntA = p.TAp >> 5, ntB = p.TBp >> 5;
+    const float inv_t = 1.f / fabsf(p.t[0]);
+
+    // this wave's A tiles: slots 0,1 <-> tiles w, w+4
+    bf16x8 afr[2][8];
+    uint32_t wA[2];
+    int nA = 0;
+    for (int tt = 0; tt < ntA; ++tt) nA += __popc(p.mwA[(size_t)i * ntA + tt]);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int at = w + 4 * sl;
+        wA[sl] = (at < ntA) ? p.mwA[(size_t)i * ntA + at] : 0u;
+        const uint16_t* src = p.hnA + ((size_t)i * p.TAp + (size_t)min(at, ntA - 1) * 32 + c) * FD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) afr[sl][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+    }
+
+    for (int j = j_begin; j < j_end; ++j) {
+        // ---- stage hB[j] into the swizzled LDS image ----
+        int nB = 0, last_tile = -1;
+        for (int tt = 0; tt < ntB; ++tt) {
+            const uint32_t wd = p.mwB[(size_t)j * ntB + tt];
+            nB += __popc(wd);
+            if (wd) last_tile = tt;
+        }
+        __syncthreads();  // previous pair done with the image and colpart
+        {
+            const int nchunks = (last_tile + 1) * 32 * 16;
+            const uint4* src = reinterpret_cast<const uint4*>(p.hnB + (size_t)j * p.TBp * FD);
+            for (int g = tid; g < nchunks; g += 256) {
+                const int row = g >> 4, ch = g & 15;
+                *reinterpret_cast<uint4*>(smem + LDS_IMG + row * ROWB + ((ch ^ (row & 15)) << 4)) = src[g];
+            }
+        }
+        __syncthreads();
+
+        float M[2][16];
+        int MI[2][16];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { M[sl][r] = -FLT_MAX; MI[sl][r] = 0; }
+
+        for (int bt = 0; bt <= last_tile; ++bt) {
+            const uint32_t wB = p.mwB[(size_t)j * ntB + bt];
+            if (wB == 0) continue;
+            bf16x8 bfr[8];
+            {
+                const int row = bt * 32 + c;
+                const unsigned char* base = smem + LDS_IMG + row * ROWB;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(base + (((2 * s + h) ^ (c & 15)) << 4));
+            }
+            float cbest = -FLT_MAX;
+            int carg = 0;
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                if (wA[sl] == 0) continue;
+                const int at = w + 4 * sl;
+                f32x16 acc;
+                if (wA[sl] == 0xffffffffu && wB == 0xffffffffu) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                } else {
+                    const float colbias = ((wB >> c) & 1u) ? 0.f : -FLT_MAX;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = ((wA[sl] >> acc_row(r, h)) & 1u) ? colbias : -FLT_MAX;
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[sl][s], bfr[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool up = acc[r] > M[sl][r];
+                    M[sl][r] = up ? acc[r] : M[sl][r];
+                    MI[sl][r] = up ? bt : MI[sl][r];
+                    const bool upc = acc[r] > cbest;
+                    cbest = upc ? acc[r] : cbest;
+                    carg = upc ? (at * 32 + acc_row(r, h)) : carg;
+                }
+            }
+            {
+                const float ob = __shfl_xor(cbest, 32);
+                const int oa = __shfl_xor(carg, 32);
+                if (ob > cbest || (ob == cbest && oa < carg)) { cbest = ob; carg = oa; }
+                if (h == 0) colpart[w * 256 + bt * 32 + c] = make_float2(cbest, __int_as_float(carg));
+            }
+        }
+
+        // ---- rows: reduce each register across the 32 lanes of its half (value + arg) ----
+        float rs = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int at = w + 4 * sl;
+            if (wA[sl] == 0) {  // tile of padding only: its arg-max slots are defined (zero), nothing else to do
+                if (p.argA && at < ntA && c < 16) p.argA[((size_t)i * p.Bc + j) * p.TAp + at * 32 + acc_row(c, h)] = 0;
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = M[sl][r];
+                int b = MI[sl][r] * 32 + c;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    const float ov = __shfl_xor(v, o);
+                    const int ob = __shfl_xor(b, o);
+                    if (ov > v || (ov == v && ob < b)) { v = ov; b = ob; }
+                }
+                const int arow = acc_row(r, h);
+                const bool valid = (wA[sl] >> arow) & 1u;
+                rs += valid ? v : 0.f;
+                if (p.argA && c == r) p.argA[((size_t)i * p.Bc + j) * p.TAp + at * 32 + arow] = valid ? (uint16_t)b : (uint16_t)0;
+            }
+        }
+        rs += __shfl_xor(rs, 32);
+        if (lane == 0) rsum[w] = rs;
+        __syncthreads();
+
+        // ---- columns: merge the four waves' partial maxima, masked sum ----
+        float cv = 0.f;
+        if (tid < p.TBp) {
+            const int bt = tid >> 5;
+            const uint32_t wB = p.mwB[(size_t)j * ntB + bt];
+            const bool valid = (wB >> (tid & 31)) & 1u;
+            float best = -FLT_MAX;
+            int arg = 0;
+            if (valid) {
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const float2 q = colpart[ww * 256 + tid];
+                    const int qa = __float_as_int(q.y);
+                    if (q.x > best || (q.x == best && qa < arg)) { best = q.x; arg = qa; }
+                }
+                cv = best;
+            }
+            if (p.argB) p.argB[((size_t)i * p.Bc + j) * p.TBp + tid] = (uint16_t)arg;
+        }
+        cv = wave_sum(cv);
+        if (lane == 0) red[w] = cv;
+        __syncthreads();
+        if (tid == 0) {
+            const float sa = rsum[0] + rsum[1] + rsum[2] + rsum[3];
+            const float sb = red[0] + red[1] + red[2] + red[3];
+            p.simA[(size_t)i * p.Bc + j] = sa / fmaxf((float)nA, 1e-6f) * inv_t;
+            p.simB[(size_t)i * p.Bc + j] = sb / fmaxf((float)nB, 1e-6f) * inv_t;
+        }
+    }
+}
+
+// ---- backward of the scores: arg-max routed gather/scatter ---------------------------------
+// One workgroup owns one "own" sequence and keeps its whole [Tp][128] f32 gradient in LDS;
+// it walks every partner sequence, and for each pair adds
+//   own[a]       += w1 * partner[arg1[a]]      (own-side max terms)
+//   own[arg2[b]] += w2 * partner[b]            (partner-side max terms that chose a)
+// with LDS float atomics.  16 lanes move one 256-B bf16 row.
+struct FilipBwdArgs {
+    const uint16_t* hnP;   // partner images [Np][TPp][128]
+    const uint32_t* mwO;   // own mask words [No][ntO]
+    const uint32_t* mwP;   // partner mask words
+    int No, TOp, Np, TPp;
+    const uint16_t* arg1;  // [pair][TOp]  partner token chosen by each own token
+    const uint16_t* arg2;  // [pair][TPp]  own token chosen by each partner token
+    const float* g1;       // d loss / d sim of the own-side score, [pair]
+    const float* g2;       // d loss / d sim of the partner-side score, [pair]
+    size_t so, sp;         // pair index = own*so + partner*sp
+    const float* t;
+    float* dn;             // [No][TOp][128] f32 out
+};
+
+__global__ __launch_bounds__(256) void filip_bwd_kernel(FilipBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* acc = reinterpret_cast<float*>(smem);  // [TOp][128]
+    const int tid = threadIdx.x;
+    const int o = blockIdx.x;
+    const int ntO = p.TOp >> 5, ntP = p.TPp >> 5;
+    for (int k = tid; k < p.TOp * FD; k += 256) acc[k] = 0.f;
+    int nO = 0;
+    for (int tt = 0; tt < ntO; ++tt) nO += __popc(p.mwO[(size_t)o * ntO + tt]);
+    const float inv_t = 1.f / fabsf(p.t[0]);
+    const int grp = tid >> 4, l16 = tid & 15;  // 16 row groups of 16 lanes
+    __syncthreads();
+    for (int q = 0; q < p.Np; ++q) {
+        const size_t pair = (size_t)o * p.so + (size_t)q * p.sp;
+        int nP = 0;
+        for (int tt = 0; tt < ntP; ++tt) nP += __popc(p.mwP[(size_t)q * ntP + tt]);
+        const float w1 = p.g1[pair] / fmaxf((float)nO, 1e-6f) * inv_t;
+        const float w2 = p.g2[pair] / fmaxf((float)nP, 1e-6f) * inv_t;
+        const uint16_t* a1 = p.arg1 + pair * p.TOp;
+        const uint16_t* a2 = p.arg2 + pair * p.TPp;
+        const uint16_t* img = p.hnP + (size_t)q * p.TPp * FD;
+        if (nP > 0) {
+            for (int a = grp; a < p.TOp; a += 16) {
+                if (!((p.mwO[(size_t)o * ntO + (a >> 5)] >> (a & 31)) & 1u)) continue;
+                const int b = a1[a];
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(img + (size_t)b * FD + l16 * 8);
+                float* dst = acc + a * FD + l16 * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(dst + e, w1 * (float)v[e]);
+            }
+        }
+        if (nO > 0) {
+            for (int b = grp; b < p.TPp; b += 16) {
+                if (!((p.mwP[(size_t)q * ntP + (b >> 5)] >> (b & 31)) & 1u)) continue;
+                const int a = a2[b];
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(img + (size_t)b * FD + l16 * 8);
+                float* dst = acc + a * FD + l16 * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(dst + e, w2 * (float)v[e]);
+            }
+        }
+    }
+    __syncthreads();
+    float* out = p.dn + (size_t)o * p.TOp * FD;
+    for (int k = tid; k < p.TOp * FD; k += 256) out[k] = acc[k];
+}
+
+// dt += -(1/t) * sum(gA*simA + gB*simB)
+__global__ __launch_bounds__(256) void filip_dt_kernel(const float* __restrict__ gA, const float* __restrict__ gB, const float* __restrict__ sA,
+                                                       const float* __restrict__ sB, size_t n, const float* __restrict__ t,
+                                                       float* __restrict__ dt) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) acc += gA[k] * sA[k] + gB[k] * sB[k];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dt, -(red[0] + red[1] + red[2] + red[3]) / t[0]);
+}
+
+// ---- host side -------------------------------------------------------------------------
+static int filip_dims_ok(const char* who, int B, int T, int d) {
+    PCLIP_REQUIRE(B >= 1 && T >= 1 && T <= PCLIP_FILIP_MAX_T, "%s: B=%d T=%d (need 1 <= T <= %d)", who, B, T, PCLIP_FILIP_MAX_T);
+    PCLIP_REQUIRE(d >= 1 && d <= PCLIP_FILIP_MAX_D, "%s: d=%d (need 1 <= d <= %d)", who, d, PCLIP_FILIP_MAX_D);
+    return PCLIP_OK;
+}
+
+extern "C" int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, int normalise, int negate, uint16_t* hn,
+                                uint32_t* maskw, void* stream) {
+    PCLIP_REQUIRE(h && mask && hn && maskw, "filip_prep: null pointer");
+    if (int rc = filip_dims_ok("filip_prep", B, T, d)) return rc;
+    const int Tp = (T + 31) / 32 * 32;
+    hipLaunchKernelGGL(filip_prep_kernel, dim3(B * (Tp / 32)), dim3(256), 0, (hipStream_t)stream, h, mask, B, T, d, Tp, normalise, negate, hn,
+                       maskw);
+    return pclip_check_launch("filip_prep_kernel");
+}
+
+extern "C" int pclip_filip_prep_bwd(const float* h, const float* dn, int B, int T, int d, int normalise, int negate, int accumulate, float* dh,
+                                    void* stream) {
+    PCLIP_REQUIRE(h && dn && dh, "filip_prep_bwd: null pointer");
+    if (int rc = filip_dims_ok("filip_prep_bwd", B, T, d)) return rc;
+    const int Tp = (T + 31) / 32 * 32;
+    const size_t rows = (size_t)B * T;
+    hipLaunchKernelGGL(filip_prep_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, dn, B, T, d, Tp, normalise,
+                       negate, accumulate, dh);
+    return pclip_check_launch("filip_prep_bwd_kernel");
+}
+
+extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
+                                   int Bc, int TB, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, void* stream) {
+    PCLIP_REQUIRE(hnA && maskwA && hnB && maskwB && t && sim_A && sim_B, "filip_sim_fwd: null pointer");
+    PCLIP_REQUIRE((argA == nullptr) == (argB == nullptr), "filip_sim_fwd: pass both argA and argB or neither");
+    if (int rc = filip_dims_ok("filip_sim_fwd", Br, TA, FD)) return rc;
+    if (int rc = filip_dims_ok("filip_sim_fwd", Bc, TB, FD)) return rc;
+    FilipArgs a;
+    a.hnA = hnA; a.mwA = maskwA; a.Br = Br; a.TAp = (TA + 31) / 32 * 32;
+    a.hnB = hnB; a.mwB = maskwB; a.Bc = Bc; a.TBp = (TB + 31) / 32 * 32;
+    a.t = t; a.simA = sim_A; a.simB = sim_B; a.argA = argA; a.argB = argB;
+    // enough workgroups to fill 256 CUs twice over several times, but at least 8 B sequences each
+    int nchunk = (2048 + Br - 1) / Br;
+    if (nchunk < 1) nchunk = 1;
+    int jchunk = (Bc + nchunk - 1) / nchunk;
+    if (jchunk < 8) jchunk = Bc < 8 ? Bc : 8;
+    nchunk = (Bc + jchunk - 1) / jchunk;
+    a.jchunk = jchunk;
+    static bool lds_set = false;
+    if (!lds_set) {
+        if (hipFuncSetAttribute((const void*)filip_sim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
+            return pclip_fail(PCLIP_ELAUNCH, "filip_sim_kernel: cannot raise the dynamic LDS limit");
+        lds_set = true;
+    }
+    hipLaunchKernelGGL(filip_sim_kernel, dim3(Br * nchunk), dim3(256), LDS_TOTAL, (hipStream_t)stream, a);
+    return pclip_check_launch("filip_sim_kernel");
+}
+
+extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
+                                   int Bc, int TB, const float* t, const float* sim_A, const float* sim_B, const uint16_t* argA,
+                                   const uint16_t* argB, const float* gA, const float* gB, float* dnA, float* dnB, float* dt, void* stream) {
+    PCLIP_REQUIRE(hnA && maskwA && hnB && maskwB && t && sim_A && sim_B && argA && argB && gA && gB && dnA && dnB && dt,
+                  "filip_sim_bwd: null pointer");
+    if (int rc = filip_dims_ok("filip_sim_bwd", Br, TA, FD)) return rc;
+    if (int rc = filip_dims_ok("filip_sim_bwd", Bc, TB, FD)) return rc;
+    const int TAp = (TA + 31) / 32 * 32, TBp = (TB + 31) / 32 * 32;
+    hipStream_t st = (hipStream_t)stream;
+    static bool lds_set = false;
+    if (!lds_set) {
+        if (hipFuncSetAttribute((const void*)filip_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * FD * 4) != hipSuccess)
+            return pclip_fail(PCLIP_ELAUNCH, "filip_bwd_kernel: cannot raise the dynamic LDS limit");
+        lds_set = true;
+    }
+    FilipBwdArgs a;
+    // d/d A images: own = A(i), partner = B(j), pair = i*Bc + j
+    a.hnP = hnB; a.mwO = maskwA; a.mwP = maskwB; a.No = Br; a.TOp = TAp; a.Np = Bc; a.TPp = TBp;
+    a.arg1 = argA; a.arg2 = argB; a.g1 = gA; a.g2 = gB; a.so = (size_t)Bc; a.sp = 1; a.t = t; a.dn = dnA;
+    hipLaunchKernelGGL(filip_bwd_kernel, dim3(Br), dim3(256), (size_t)TAp * FD * 4, st, a);
+    if (int rc = pclip_check_launch("filip_bwd_kernel(A)")) return rc;
+    // d/d B images: own = B(j), partner = A(i), pair = i*Bc + j
+    a.hnP = hnA; a.mwO = maskwB; a.mwP = maskwA; a.No = Bc; a.TOp = TBp; a.Np = Br; a.TPp = TAp;
+    a.arg1 = argB; a.arg2 = argA; a.g1 = gB; a.g2 = gA; a.so = 1; a.sp = (size_t)Bc; a.dn = dnB;
+    hipLaunchKernelGGL(filip_bwd_kernel, dim3(Bc), dim3(256), (size_t)TBp * FD * 4, st, a);
+    if (int rc = pclip_check_launch("filip_bwd_kernel(B)")) return rc;
+    const size_t n = (size_t)Br * Bc;
+    const int blocks = (int)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
+    hipLaunchKernelGGL(filip_dt_kernel, dim3(blocks), dim3(256), 0, st, gA, gB, sim_A, sim_B, n, t, dt);
+    return pclip_check_launch("filip_dt_kernel");
+}

@@ -1,0 +1,54 @@
+// Shared host/device helpers for the pclip kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/pclip.h"
+
+#ifndef FLT_MAX
+#define FLT_MAX 3.402823466e+38f
+#endif
+
+// ---- host side -------------------------------------------------------------------------
+extern thread_local char g_pclip_err[512];
+
+inline int pclip_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_pclip_err, sizeof(g_pclip_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define PCLIP_REQUIRE(cond, ...)                                  \
+    do {                                                          \
+        if (!(cond)) return pclip_fail(PCLIP_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+inline int pclip_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return pclip_fail(PCLIP_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return PCLIP_OK;
+}
+
+inline size_t pclip_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device side -----------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Row of a 32x32 MFMA accumulator tile held in register `reg` (0..15) by lane half `h` (0/1).
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

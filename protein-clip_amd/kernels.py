@@ -1,0 +1,225 @@
+"""Tensor-level wrappers over the C ABI (include/pclip.h): argument checks, output and
+workspace allocation through torch, one C call each.  No arithmetic happens here."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_gpu_tensor, stream_of
+
+F32 = torch.float32
+_ws_cache = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    """A per-device scratch buffer that only ever grows (reused across calls on a stream)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _scalar(t, device, name):
+    """Temperature / upstream-gradient scalars live on the device: accept a 0-d or 1-element
+    GPU tensor, or a Python float (copied once)."""
+    if isinstance(t, torch.Tensor):
+        if t.numel() != 1:
+            raise _lib.PclipError(f"{name}: expected a scalar tensor")
+        t = t.detach().reshape(1)
+        if not t.is_cuda or t.dtype != F32:
+            t = t.to(device=device, dtype=F32)
+        return t.contiguous()
+    return torch.tensor([float(t)], dtype=F32, device=device)
+
+
+# ---- L2 normalise + scale ---------------------------------------------------------------
+def l2norm_scale_fwd(e: torch.Tensor, t) -> torch.Tensor:
+    require_gpu_tensor(e, F32, "e")
+    B, d = e.shape
+    tt = _scalar(t, e.device, "t")
+    x = torch.empty_like(e)
+    check(_lib.load().pclip_l2norm_scale_fwd(ptr(e), ptr(tt), ptr(x), B, d, stream_of(e)), "pclip_l2norm_scale_fwd")
+    return x
+
+
+def l2norm_scale_bwd(e, t, dx, g=None, dt: Optional[torch.Tensor] = None):
+    """Returns (de, dt); if ``dt`` (1-element f32 GPU tensor) is given it is accumulated into."""
+    require_gpu_tensor(e, F32, "e")
+    require_gpu_tensor(dx, F32, "dx")
+    B, d = e.shape
+    tt = _scalar(t, e.device, "t")
+    gg = None if g is None else _scalar(g, e.device, "g")
+    de = torch.empty_like(e)
+    if dt is None:
+        dt = torch.zeros(1, dtype=F32, device=e.device)
+    check(
+        _lib.load().pclip_l2norm_scale_bwd(ptr(e), ptr(tt), ptr(dx), 1, 0, ptr(gg), ptr(de), ptr(dt), B, d, stream_of(e)),
+        "pclip_l2norm_scale_bwd",
+    )
+    return de, dt
+
+
+# ---- CLIP -------------------------------------------------------------------------------
+def clip_fwd(X_own, Y_own, X_all, Y_all, row_offset: int = 0, logits_mode: int = 0):
+    """Returns (lse_row[Br], lse_col[Br], loss_part[1], logits or None)."""
+    for n, v in (("X_own", X_own), ("Y_own", Y_own), ("X_all", X_all), ("Y_all", Y_all)):
+        require_gpu_tensor(v, F32, n)
+    Br, d = X_own.shape
+    Bg = X_all.shape[0]
+    if Y_own.shape != X_own.shape or Y_all.shape != X_all.shape or X_all.shape[1] != d:
+        raise _lib.PclipError("clip_fwd: shape mismatch between the two sides")
+    lib = _lib.load()
+    dev = X_own.device
+    nbytes = lib.pclip_clip_workspace_bytes(Br, Bg, d)
+    ws = _workspace(dev, nbytes)
+    lse_row = torch.empty(Br, dtype=F32, device=dev)
+    lse_col = torch.empty(Br, dtype=F32, device=dev)
+    loss = torch.empty(1, dtype=F32, device=dev)
+    logits = torch.empty(Br, Bg, dtype=F32, device=dev) if logits_mode else None
+    check(
+        lib.pclip_clip_fwd(ptr(X_own), ptr(Y_own), ptr(X_all), ptr(Y_all), Br, Bg, d, row_offset, ptr(lse_row), ptr(lse_col),
+                           ptr(loss), ptr(logits), logits_mode, ptr(ws), ws.numel(), stream_of(X_own)),
+        "pclip_clip_fwd",
+    )
+    return lse_row, lse_col, loss, logits
+
+
+def clip_bwd(X_own, Y_own, X_all, Y_all, lse_row_all, lse_col_all, row_offset: int = 0, g=None):
+    """Returns (dX_own, dY_own)."""
+    Br, d = X_own.shape
+    Bg = X_all.shape[0]
+    require_gpu_tensor(lse_row_all, F32, "lse_row_all")
+    require_gpu_tensor(lse_col_all, F32, "lse_col_all")
+    if lse_row_all.numel() != Bg or lse_col_all.numel() != Bg:
+        raise _lib.PclipError("clip_bwd: lse vectors must cover the global batch")
+    lib = _lib.load()
+    dev = X_own.device
+    ws = _workspace(dev, lib.pclip_clip_workspace_bytes(Br, Bg, d))
+    gg = None if g is None else _scalar(g, dev, "g")
+    dX = torch.empty_like(X_own)
+    dY = torch.empty_like(Y_own)
+    check(
+        lib.pclip_clip_bwd(ptr(X_own), ptr(Y_own), ptr(X_all), ptr(Y_all), ptr(lse_row_all), ptr(lse_col_all), Br, Bg, d, row_offset,
+                           ptr(gg), ptr(dX), ptr(dY), ptr(ws), ws.numel(), stream_of(X_own)),
+        "pclip_clip_bwd",
+    )
+    return dX, dY
+
+
+class ClipStep:
+    """Pre-allocated fused step (normalise both towers -> loss -> all gradients) for one
+    (B, d): every buffer is created once, ``run`` only enqueues kernels."""
+
+    def __init__(self, B: int, d: int, device):
+        lib = _lib.load()
+        self.B, self.d, self.device = B, d, torch.device(device)
+        self.ws = torch.empty(lib.pclip_clip_step_workspace_bytes(B, d), dtype=torch.uint8, device=device)
+        self.loss = torch.empty(1, dtype=F32, device=device)
+        self.de_pep = torch.empty(B, d, dtype=F32, device=device)
+        self.de_rec = torch.empty(B, d, dtype=F32, device=device)
+        self.dt = torch.empty(1, dtype=F32, device=device)
+
+    def run(self, e_pep, e_rec, t, stream=None):
+        st = ctypes.c_void_p(stream) if stream is not None else stream_of(e_pep)
+        check(
+            _lib.load().pclip_clip_step(ptr(e_pep), ptr(e_rec), ptr(t), self.B, self.d, ptr(self.loss), ptr(self.de_pep),
+                                        ptr(self.de_rec), ptr(self.dt), ptr(self.ws), self.ws.numel(), st),
+            "pclip_clip_step",
+        )
+        return self.loss, self.de_pep, self.de_rec, self.dt
+
+
+def clip_step(e_pep, e_rec, t):
+    require_gpu_tensor(e_pep, F32, "e_pep")
+    require_gpu_tensor(e_rec, F32, "e_rec")
+    B, d = e_pep.shape
+    step = ClipStep(B, d, e_pep.device)
+    return step.run(e_pep, e_rec, _scalar(t, e_pep.device, "t"))
+
+
+# ---- row-wise InfoNCE -------------------------------------------------------------------
+def rowce_fwd(logits, row_offset: int = 0, Bg: Optional[int] = None, use_dcl: bool = False):
+    require_gpu_tensor(logits, F32, "logits")
+    Br, Bc = logits.shape
+    Bg = Br if Bg is None else Bg
+    lse = torch.empty(Br, dtype=F32, device=logits.device)
+    loss = torch.empty(1, dtype=F32, device=logits.device)
+    check(_lib.load().pclip_rowce_fwd(ptr(logits), Br, Bc, row_offset, Bg, int(use_dcl), ptr(lse), ptr(loss), stream_of(logits)),
+          "pclip_rowce_fwd")
+    return lse, loss
+
+
+def rowce_bwd(logits, lse, row_offset: int = 0, Bg: Optional[int] = None, use_dcl: bool = False, g=None, gscale: float = 1.0):
+    Br, Bc = logits.shape
+    Bg = Br if Bg is None else Bg
+    gg = None if g is None else _scalar(g, logits.device, "g")
+    out = torch.empty_like(logits)
+    check(_lib.load().pclip_rowce_bwd(ptr(logits), ptr(lse), Br, Bc, row_offset, Bg, int(use_dcl), ptr(gg), gscale, ptr(out),
+                                      stream_of(logits)), "pclip_rowce_bwd")
+    return out
+
+
+# ---- FILIP ------------------------------------------------------------------------------
+def _tp(T: int) -> int:
+    return (T + 31) // 32 * 32
+
+
+def filip_prep(h, mask, normalise: bool, negate: bool = False):
+    """h [B,T,d] f32, mask [B,T] (any integer/bool dtype) -> (hn [B,Tp,128] bf16 bits as int16,
+    maskw [B,Tp/32] int32)."""
+    require_gpu_tensor(h, F32, "h")
+    B, T, d = h.shape
+    m8 = (mask != 0).to(torch.uint8).contiguous()
+    if m8.shape != (B, T) or not m8.is_cuda:
+        raise _lib.PclipError("filip_prep: mask must be a GPU tensor of shape [B,T]")
+    Tp = _tp(T)
+    hn = torch.empty(B, Tp, 128, dtype=torch.int16, device=h.device)
+    mw = torch.empty(B, Tp // 32, dtype=torch.int32, device=h.device)
+    check(_lib.load().pclip_filip_prep(ptr(h), ptr(m8), B, T, d, int(normalise), int(negate), ptr(hn), ptr(mw), stream_of(h)),
+          "pclip_filip_prep")
+    return hn, mw
+
+
+def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True):
+    dev = hnA.device
+    Br, Bc = hnA.shape[0], hnB.shape[0]
+    tt = _scalar(t, dev, "t")
+    simA = torch.empty(Br, Bc, dtype=F32, device=dev)
+    simB = torch.empty(Br, Bc, dtype=F32, device=dev)
+    argA = torch.empty(Br, Bc, _tp(TA), dtype=torch.int16, device=dev) if want_arg else None
+    argB = torch.empty(Br, Bc, _tp(TB), dtype=torch.int16, device=dev) if want_arg else None
+    check(_lib.load().pclip_filip_sim_fwd(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), ptr(simA), ptr(simB),
+                                          ptr(argA), ptr(argB), stream_of(hnA)), "pclip_filip_sim_fwd")
+    return simA, simB, argA, argB
+
+
+def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt: Optional[torch.Tensor] = None):
+    dev = hnA.device
+    Br, Bc = hnA.shape[0], hnB.shape[0]
+    tt = _scalar(t, dev, "t")
+    require_gpu_tensor(gA, F32, "gA")
+    require_gpu_tensor(gB, F32, "gB")
+    dnA = torch.empty(Br, _tp(TA), 128, dtype=F32, device=dev)
+    dnB = torch.empty(Bc, _tp(TB), 128, dtype=F32, device=dev)
+    if dt is None:
+        dt = torch.zeros(1, dtype=F32, device=dev)
+    check(_lib.load().pclip_filip_sim_bwd(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), ptr(simA), ptr(simB),
+                                          ptr(argA), ptr(argB), ptr(gA), ptr(gB), ptr(dnA), ptr(dnB), ptr(dt), stream_of(hnA)),
+          "pclip_filip_sim_bwd")
+    return dnA, dnB, dt
+
+
+def filip_prep_bwd(h, dn, normalise: bool, negate: bool = False, out: Optional[torch.Tensor] = None):
+    require_gpu_tensor(h, F32, "h")
+    require_gpu_tensor(dn, F32, "dn")
+    B, T, d = h.shape
+    acc = out is not None
+    dh = out if acc else torch.empty_like(h)
+    check(_lib.load().pclip_filip_prep_bwd(ptr(h), ptr(dn), B, T, d, int(normalise), int(negate), int(acc), ptr(dh), stream_of(h)),
+          "pclip_filip_prep_bwd")
+    return dh

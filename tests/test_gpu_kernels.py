@@ -1,0 +1,322 @@
+"""GPU parity tests of the HIP kernels, called through the C ABI (ctypes) and checked against
+the CPU oracle and the reference-generated golden vectors.  Run with ``-m gpu`` on an MI355X."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_flat
+from oracle import pclip_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import protein_clip_amd.kernels as kernels
+    from protein_clip_amd import _lib
+    assert _lib.load().pclip_check_device(0) == 0, _lib.load().pclip_last_error()
+    return kernels
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def close(a, b, rtol, atol):
+    torch.testing.assert_close(a.detach().cpu().float().reshape(b.shape), b.float(), rtol=rtol, atol=atol)
+
+
+def mostly_close(a, b, rtol, atol, max_bad_frac=0.0, max_rel_l2=None):
+    """Elementwise closeness with a budget of outliers (arg-max near-ties route a gradient row
+    to a different, equally good partner) and an overall relative L2 bound."""
+    a = a.detach().cpu().double().reshape(b.shape)
+    b = b.double()
+    bad = (a - b).abs() > (atol + rtol * b.abs())
+    frac = bad.double().mean().item()
+    assert frac <= max_bad_frac, f"{frac:.4%} of elements outside tolerance (budget {max_bad_frac:.4%})"
+    if max_rel_l2 is not None:
+        rel = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+        assert rel <= max_rel_l2, f"relative L2 error {rel:.3e} > {max_rel_l2:.1e}"
+
+
+# ------------------------------------------------------------------------------------------
+# L2 normalise + scale
+# ------------------------------------------------------------------------------------------
+def test_l2norm_scale_matches_golden(K, clip_cases):
+    for key, c in clip_cases.items():
+        x = K.l2norm_scale_fwd(dev(c["e_pep"]), dev(c["t"].reshape(1)))
+        close(x, c["x"], 1e-6, 1e-7)
+
+
+def test_l2norm_scale_bwd_matches_autograd(K):
+    g = torch.Generator().manual_seed(7)
+    for B, d in [(5, 8), (33, 128), (64, 100), (3, 1000)]:
+        e = torch.randn(B, d, generator=g)
+        dx = torch.randn(B, d, generator=g)
+        t = torch.tensor(0.8)
+        e_ = e.clone().requires_grad_(True)
+        t_ = t.clone().requires_grad_(True)
+        (O.l2norm_scale(e_, t_) * dx).sum().backward()
+        de, dt = K.l2norm_scale_bwd(dev(e), dev(t.reshape(1)), dev(dx))
+        close(de, e_.grad, 1e-4, 1e-6)
+        close(dt, t_.grad.reshape(1), 1e-4, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------
+# CLIP
+# ------------------------------------------------------------------------------------------
+def test_clip_fwd_matches_golden(K, clip_cases):
+    for key, c in clip_cases.items():
+        x, y = dev(c["x"]), dev(c["y"])
+        lse_r, lse_c, loss, logits = K.clip_fwd(x, y, x, y, 0, logits_mode=1)
+        close(loss, c["loss"].reshape(1), 1e-5, 1e-6)
+        close(logits, c["logits"], 1e-5, 2e-6)
+        close(lse_r, torch.logsumexp(c["logits"], 1), 1e-5, 2e-6)
+        close(lse_c, torch.logsumexp(c["logits"], 0), 1e-5, 2e-6)
+        _, _, _, e_logits = K.clip_fwd(x, y, x, y, 0, logits_mode=2)
+        close(e_logits, c["exp_logits"], 1e-5, 1e-6)
+
+
+def test_clip_bwd_matches_oracle_autograd(K, clip_cases):
+    for key, c in clip_cases.items():
+        x = c["x"].clone().requires_grad_(True)
+        y = c["y"].clone().requires_grad_(True)
+        (O.clip_contrastive_loss(x, y.t()) * 3.0).backward()
+        xd, yd = dev(c["x"]), dev(c["y"])
+        lse_r, lse_c, _, _ = K.clip_fwd(xd, yd, xd, yd)
+        dX, dY = K.clip_bwd(xd, yd, xd, yd, lse_r, lse_c, 0, g=torch.tensor([3.0]))
+        close(dX, x.grad, 1e-4, 1e-7)
+        close(dY, y.grad, 1e-4, 1e-7)
+
+
+def test_clip_step_matches_golden(K, clip_cases):
+    for key, c in clip_cases.items():
+        loss, dp, dr, dt = K.clip_step(dev(c["e_pep"]), dev(c["e_rec"]), dev(c["t"].reshape(1)))
+        close(loss, c["loss"].reshape(1), 1e-5, 1e-6)
+        close(dp, c["d_e_pep"], 1e-4, 2e-7)
+        close(dr, c["d_e_rec"], 1e-4, 2e-7)
+        close(dt, c["d_t"].reshape(1), 1e-4, 2e-6)
+
+
+def test_clip_benchmark_size_scalars(K):
+    g = load_flat("clip_scalars.npz")
+    for B in (256, 1024):
+        gen = torch.Generator().manual_seed(0)
+        e_pep = torch.randn(B, 128, generator=gen)
+        e_rec = torch.randn(B, 128, generator=gen)
+        loss, dp, dr, dt = K.clip_step(dev(e_pep), dev(e_rec), dev(torch.tensor([1.0])))
+        close(loss, g[f"loss_B{B}"].reshape(1), 1e-5, 1e-5)
+        ol, odp, odr, odt = O.clip_step_analytic(e_pep.double(), e_rec.double(), torch.tensor(1.0, dtype=torch.float64))
+        close(dp, odp.float(), 1e-4, 1e-8)
+        close(dr, odr.float(), 1e-4, 1e-8)
+        close(dt, odt.float().reshape(1), 1e-4, 1e-6)
+        # size-independent property: the gradient of the loss w.r.t. every logit sums to zero per
+        # row block, so d e . e = 0 for each row (the normalise Jacobian kills the radial part)
+        radial = (dp.cpu() * e_pep).sum(-1).abs().max().item()
+        assert radial < 1e-6
+
+
+def test_clip_sharded_rows_equal_single_device(K):
+    """Two 'ranks' each owning half the rows reproduce the one-device result exactly as the
+    multi-GPU path assembles it: lse vectors concatenated, loss parts summed."""
+    gen = torch.Generator().manual_seed(3)
+    B, d = 96, 128
+    x = O.l2norm_scale(torch.randn(B, d, generator=gen), torch.tensor(1.0))
+    y = O.l2norm_scale(torch.randn(B, d, generator=gen), torch.tensor(1.0))
+    xd, yd = dev(x), dev(y)
+    lse_r, lse_c, loss, _ = K.clip_fwd(xd, yd, xd, yd)
+    dX, dY = K.clip_bwd(xd, yd, xd, yd, lse_r, lse_c)
+    parts = []
+    for r, (lo, hi) in enumerate([(0, 40), (40, 96)]):
+        xo, yo = xd[lo:hi].contiguous(), yd[lo:hi].contiguous()
+        parts.append((lo, hi, xo, yo) + K.clip_fwd(xo, yo, xd, yd, lo)[:3])
+    lr = torch.cat([p[4] for p in parts]); lc = torch.cat([p[5] for p in parts])
+    close(lr, lse_r.cpu(), 1e-6, 1e-6)
+    close(lc, lse_c.cpu(), 1e-6, 1e-6)
+    close(sum(p[6] for p in parts), loss.cpu(), 1e-6, 1e-6)
+    for lo, hi, xo, yo, *_ in parts:
+        dXo, dYo = K.clip_bwd(xo, yo, xd, yd, lr, lc, lo)
+        close(dXo, dX[lo:hi].cpu(), 1e-5, 1e-8)
+        close(dYo, dY[lo:hi].cpu(), 1e-5, 1e-8)
+
+
+def test_clip_rejects_bad_arguments(K):
+    from protein_clip_amd._lib import PclipError
+    x = torch.randn(8, 130, device="cuda")
+    with pytest.raises(PclipError):
+        K.clip_fwd(x, x, x, x)            # d not a multiple of 4 / too wide
+    with pytest.raises(PclipError):
+        K.l2norm_scale_fwd(torch.randn(4, 8), 1.0)   # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------------------------------
+# row-wise InfoNCE
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("use_dcl", [False, True])
+def test_rowce_matches_oracle(K, use_dcl):
+    gen = torch.Generator().manual_seed(11)
+    for B in (3, 16, 200):
+        logits = torch.randn(B, B, generator=gen) * 3
+        l_ = logits.clone().requires_grad_(True)
+        loss_ref = O.row_ce(l_, use_dcl)
+        (loss_ref * 0.5).backward()
+        lse, loss = K.rowce_fwd(dev(logits), use_dcl=use_dcl)
+        close(loss, loss_ref.detach().reshape(1), 1e-5, 1e-6)
+        dl = K.rowce_bwd(dev(logits), lse, use_dcl=use_dcl, gscale=0.5)
+        close(dl, l_.grad, 1e-4, 1e-8)
+
+
+def test_rowce_uniform_logits_give_log_B(K):
+    lse, loss = K.rowce_fwd(torch.zeros(64, 64, device="cuda"))
+    close(loss, torch.tensor([math.log(64.0)]), 1e-6, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------
+# FILIP
+# ------------------------------------------------------------------------------------------
+def _filip_fwd(K, hA, hB, mA, mB, t, normalise):
+    neg = bool(t < 0)
+    hnA, mwA = K.filip_prep(dev(hA), dev(mA), normalise, negate=neg)
+    hnB, mwB = K.filip_prep(dev(hB), dev(mB), normalise)
+    out = K.filip_sim_fwd(hnA, mwA, hA.shape[1], hnB, mwB, hB.shape[1], dev(t.reshape(1)))
+    return (hnA, mwA, hnB, mwB) + out
+
+
+def test_filip_prep_layout(K):
+    gen = torch.Generator().manual_seed(5)
+    h = torch.randn(3, 37, 20, generator=gen)
+    m = (torch.rand(3, 37, generator=gen) > 0.3).to(torch.uint8)
+    hn, mw = K.filip_prep(dev(h), dev(m), True)
+    assert hn.shape == (3, 64, 128) and mw.shape == (3, 2)
+    got = hn.cpu().view(torch.bfloat16).float()
+    want = torch.zeros(3, 64, 128)
+    want[:, :37, :20] = O.bf16_round(O.filip_normalise(h)) * m[..., None]
+    close(got, want, 0, 0)
+    bits = mw.cpu().to(torch.int64) & 0xFFFFFFFF
+    for b in range(3):
+        for tok in range(64):
+            on = tok < 37 and bool(m[b, tok])
+            assert ((int(bits[b, tok // 32]) >> (tok % 32)) & 1) == int(on)
+
+
+def test_filip_scores_match_golden(K, filip_cases):
+    for key, c in filip_cases.items():
+        pre = key.endswith("bf16n")
+        res = _filip_fwd(K, c["hA"], c["hB"], c["maskA"], c["maskB"], c["t"], normalise=not pre)
+        simA, simB = res[4], res[5]
+        tol = 2e-6 if pre else 2e-3   # bf16-exact operands vs operands rounded to bf16 after normalising
+        close(simA, c["sim_A"], tol, tol)
+        close(simB, c["sim_B"], tol, tol)
+
+
+def test_filip_argmax_points_at_the_maximum(K, filip_cases):
+    c = filip_cases["s3_B8_TA48_TB40_d128_bf16n"]
+    hA, hB, mA, mB, t = c["hA"], c["hB"], c["maskA"].bool(), c["maskB"].bool(), c["t"]
+    res = _filip_fwd(K, hA, hB, c["maskA"], c["maskB"], t, normalise=False)
+    argA, argB = res[6].cpu().long(), res[7].cpu().long()
+    sim = torch.einsum("iad,jbd->ijab", hA, hB)
+    sim = sim.masked_fill(~(mA[:, None, :, None] & mB[None, :, None, :]), float("-inf"))
+    rA = sim.amax(3)
+    pickA = torch.gather(sim, 3, argA[:, :, :48, None]).squeeze(3)
+    ok = mA[:, None, :].expand_as(rA)
+    assert torch.allclose(pickA[ok], rA[ok], rtol=0, atol=2e-6)
+    rB = sim.amax(2)
+    pickB = torch.gather(sim, 2, argB[:, :, None, :40]).squeeze(2)
+    okb = mB[None, :, :].expand_as(rB)
+    assert torch.allclose(pickB[okb], rB[okb], rtol=0, atol=2e-6)
+
+
+def _oracle_filip_grads(hA, hB, mA, mB, t, normalise, gA, gB):
+    """Oracle gradients of sum(gA*sim_A + gB*sim_B) with the operands rounded to bf16 after the
+    optional normalisation (straight-through), i.e. what the matrix cores are fed."""
+    a = hA.clone().requires_grad_(True)
+    b = hB.clone().requires_grad_(True)
+    tt = t.clone().requires_grad_(True)
+    na = O.filip_normalise(a) if normalise else a
+    nb = O.filip_normalise(b) if normalise else b
+    na = na + (O.bf16_round(na.detach()) - na.detach())
+    nb = nb + (O.bf16_round(nb.detach()) - nb.detach())
+    sA, sB = O.filip_similarity_block(na, nb, mA, mB, tt)
+    ((sA * gA).sum() + (sB * gB).sum()).backward()
+    # the reference gives masked tokens a zero gradient; so does the kernel
+    return sA.detach(), sB.detach(), a.grad, b.grad, tt.grad
+
+
+def test_filip_backward_matches_oracle(K, filip_cases):
+    gen = torch.Generator().manual_seed(21)
+    for key, c in filip_cases.items():
+        pre = key.endswith("bf16n")
+        hA, hB, mA, mB, t = c["hA"], c["hB"], c["maskA"], c["maskB"], c["t"]
+        B = hA.shape[0]
+        gA = torch.randn(B, B, generator=gen)
+        gB = torch.randn(B, B, generator=gen)
+        sA, sB, dA_ref, dB_ref, dt_ref = _oracle_filip_grads(hA, hB, mA, mB, t, not pre, gA, gB)
+        hnA, mwA, hnB, mwB, simA, simB, argA, argB = _filip_fwd(K, hA, hB, mA, mB, t, normalise=not pre)
+        close(simA, sA, 2e-6, 2e-6)
+        close(simB, sB, 2e-6, 2e-6)
+        dnA, dnB, dt = K.filip_sim_bwd(hnA, mwA, hA.shape[1], hnB, mwB, hB.shape[1], dev(t.reshape(1)), simA, simB, argA, argB,
+                                       dev(gA), dev(gB))
+        dA = K.filip_prep_bwd(dev(hA), dnA, normalise=not pre)
+        dB = K.filip_prep_bwd(dev(hB), dnB, normalise=not pre)
+        mostly_close(dA, dA_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)
+        mostly_close(dB, dB_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)
+        close(dt, dt_ref.reshape(1), 1e-4, 1e-5)
+
+
+def test_filip_negative_temperature(K, filip_cases):
+    c = filip_cases["s1_B6_TA9_TB11_d16_raw"]
+    t = torch.tensor(-0.9)
+    sA, sB = O.filip_similarity(O.bf16_round(O.filip_normalise(c["hA"])), O.bf16_round(O.filip_normalise(c["hB"])),
+                                c["maskA"], c["maskB"], t)
+    res = _filip_fwd(K, c["hA"], c["hB"], c["maskA"], c["maskB"], t, normalise=True)
+    close(res[4], sA, 2e-6, 2e-6)
+    close(res[5], sB, 2e-6, 2e-6)
+
+
+def test_filip_all_padding_sequence(K):
+    """A sequence with no valid token: the reference fills its pairs with finfo.min; sums of
+    those overflow to -inf on the side that averages over the OTHER sequence's tokens, and the
+    empty side averages to zero."""
+    gen = torch.Generator().manual_seed(9)
+    hA = torch.randn(3, 6, 16, generator=gen); hB = torch.randn(3, 5, 16, generator=gen)
+    mA = torch.ones(3, 6, dtype=torch.uint8); mB = torch.ones(3, 5, dtype=torch.uint8)
+    mB[1] = 0
+    t = torch.tensor(1.0)
+    sA, sB = O.filip_similarity(O.bf16_round(O.filip_normalise(hA)), O.bf16_round(O.filip_normalise(hB)), mA, mB, t)
+    res = _filip_fwd(K, hA, hB, mA, mB, t, normalise=True)
+    gotA, gotB = res[4].cpu(), res[5].cpu()
+    assert torch.isinf(sA[:, 1]).all() and torch.isinf(gotA[:, 1]).all() and (gotA[:, 1] < 0).all()
+    assert (sB[:, 1] == 0).all() and (gotB[:, 1] == 0).all()
+    keep = [0, 2]
+    close(gotA[:, keep], sA[:, keep], 2e-6, 2e-6)
+    close(gotB[:, keep], sB[:, keep], 2e-6, 2e-6)
+
+
+def test_filip_benchmark_size_matches_reference_scores(K):
+    """B = 256, L = 256, d = 128: every one of the 2 x 65,536 scores against the reference's
+    (generated block-wise by oracle/gen_golden.py), plus the loss through the row-CE kernels."""
+    g = load_flat("filip_b256_l256.npz")
+    B, L, d = 256, 256, 128
+    gen = torch.Generator().manual_seed(0)
+    hA = O.bf16_round(torch.randn(B, L, d, generator=gen))
+    hB = O.bf16_round(torch.randn(B, L, d, generator=gen))
+    lA = torch.randint(128, 257, (B,), generator=gen)
+    lB = torch.randint(128, 257, (B,), generator=gen)
+    mA, mB = O.right_padded_masks(lA, L), O.right_padded_masks(lB, L)
+    res = _filip_fwd(K, hA, hB, mA, mB, torch.tensor(1.0), normalise=True)
+    simA, simB = res[4], res[5]
+    close(simA, g["sim_A"], 2e-3, 2e-3)
+    close(simB, g["sim_B"], 2e-3, 2e-3)
+    _, lossA = K.rowce_fwd(simA)
+    _, lossB = K.rowce_fwd(simB)
+    close((lossA + lossB) / 2, g["loss"].reshape(1), 1e-3, 1e-3)
+    # size-independent properties: transposing the roles of the two sides transposes the scores
+    res_t = _filip_fwd(K, hB, hA, mB, mA, torch.tensor(1.0), normalise=True)
+    assert torch.equal(res_t[5].t().contiguous(), simA) or torch.allclose(res_t[5].t(), simA, atol=1e-6)
+    assert torch.allclose(res_t[4].t(), simB, atol=1e-6)
+    # and the scores of a sub-batch are the corresponding block of the full result
+    sub = _filip_fwd(K, hA[:16], hB[32:48], mA[:16], mB[32:48], torch.tensor(1.0), normalise=True)
+    assert torch.allclose(sub[4], simA[:16, 32:48], atol=1e-6) and torch.allclose(sub[5], simB[:16, 32:48], atol=1e-6)

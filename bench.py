@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the contrastive hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of BOTH workloads the headline metric names, forward + backward from
+raw head outputs to their gradients, inputs resident in HBM:
+  * CLIP  — per-GPU batch 256 (N=1; global batch 256) or 1024 (N>1; global 1024*N, i.e. 8192
+            on 8 GPUs), d = 128, f32: normalise*exp(t/2) -> symmetric InfoNCE -> backward;
+  * FILIP — per-GPU batch 256 (global 256*N, i.e. 2048 on 8 GPUs), L = 256 tokens (valid
+            lengths U[128,256]), d = 128: token normalise -> bf16-MFMA max-similarity ->
+            two row InfoNCE losses -> backward.
+``value`` = protein pairs of both global batches per second of whole-job time (max over
+ranks).  The per-workload numbers and rooflines are in ``workloads``.  Rank 0 prints ONE JSON
+line.  The CPU baseline (N=1 only) times the repository's CPU oracle on a bounded sample.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D = 128
+L = 256
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["both", "clip", "filip"], default="both")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_inputs(rank, clip_bl, filip_bl, device):
+    g = torch.Generator().manual_seed(rank)          # rank 0 == the single-GPU inputs
+    e_pep = torch.randn(clip_bl, D, generator=g)
+    e_rec = torch.randn(clip_bl, D, generator=g)
+    hA = torch.randn(filip_bl, L, D, generator=g).to(torch.bfloat16).float()
+    hB = torch.randn(filip_bl, L, D, generator=g).to(torch.bfloat16).float()
+    lA = torch.randint(128, L + 1, (filip_bl,), generator=g)
+    lB = torch.randint(128, L + 1, (filip_bl,), generator=g)
+    ar = torch.arange(L)[None]
+    mA = (ar < lA[:, None]).to(torch.uint8)
+    mB = (ar < lB[:, None]).to(torch.uint8)
+    cpu = dict(e_pep=e_pep, e_rec=e_rec, hA=hA, hB=hB, mA=mA, mB=mB, lA=lA, lB=lB)
+    dev = {k: v.to(device).contiguous() for k, v in cpu.items()}
+    return cpu, dev
+
+
+def cpu_baseline(cpu, clip_b, filip_b):
+    """Oracle (PyTorch-CPU restatement of the reference path) on the host cores: CLIP at the
+    full batch; FILIP on the first 32x32 block of sequence pairs, scaled by (B/32)^2."""
+    from oracle import pclip_oracle as O
+    t = torch.tensor(1.0)
+    ts = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        O.clip_step(cpu["e_pep"][:clip_b], cpu["e_rec"][:clip_b], t)
+        ts.append(time.perf_counter() - t0)
+    t_clip = statistics.median(ts[2:])
+    sb = 32
+    tf = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.filip_step(cpu["hA"][:sb], cpu["hB"][:sb], cpu["mA"][:sb], cpu["mB"][:sb], t, block=16)
+        tf.append(time.perf_counter() - t0)
+    t_filip = statistics.median(tf) * (filip_b / sb) ** 2
+    return {
+        "value": (clip_b + filip_b) / (t_clip + t_filip),
+        "unit": "pairs/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"CLIP B={clip_b} full step, median of 10 ({t_clip * 1e3:.3f} ms); FILIP first {sb}x{sb} sequence pairs "
+                  f"(1/{(filip_b // sb) ** 2} of the B={filip_b} step, median of 3 = {statistics.median(tf):.3f} s) scaled by "
+                  f"{(filip_b // sb) ** 2}",
+        "clip_ms": t_clip * 1e3,
+        "filip_ms_extrapolated": t_filip * 1e3,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from protein_clip_amd import _lib, kernels as K
+    from protein_clip_amd.steps import ClipShardedStep, FilipShardedStep
+    lib = _lib.load()
+    if lib.pclip_check_device(local_rank) != 0:
+        raise SystemExit(lib.pclip_last_error().decode())
+
+    clip_bl = 256 if world == 1 else 1024
+    filip_bl = 256
+    cpu, dv = make_inputs(rank, clip_bl, filip_bl, device)
+    t = torch.tensor([1.0], device=device)
+
+    clip_fused = K.ClipStep(clip_bl, D, device) if world == 1 else None
+    clip_sh = ClipShardedStep() if world > 1 else None
+    filip_sh = FilipShardedStep()
+
+    def clip_step():
+        if clip_fused is not None:
+            return clip_fused.run(dv["e_pep"], dv["e_rec"], t)
+        return clip_sh.run(dv["e_pep"], dv["e_rec"], t)
+
+    def filip_step(ev=None):
+        return filip_sh.run(dv["hA"], dv["hB"], dv["mA"], dv["mB"], t, sim_events=ev)
+
+    def bracket(fn, steps):
+        """Barrier + sync, run, sync + barrier; returns seconds (max over ranks)."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = tt.item()
+        return el
+
+    do_clip = args.workload in ("both", "clip")
+    do_filip = args.workload in ("both", "filip")
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i, ev=True):
+        if do_clip:
+            clip_step()
+        if do_filip:
+            filip_step(events[i] if ev else None)
+
+    for i in range(args.warmup):
+        step(i, ev=False)
+    total = bracket(lambda i: step(i), args.steps)
+    sim_ms = statistics.mean(e0.elapsed_time(e1) for e0, e1 in events) if do_filip else None
+
+    # per-workload brackets (same step counts), for the nested records
+    t_clip = bracket(lambda i: clip_step(), args.steps) if do_clip else None
+    t_filip = bracket(lambda i: filip_step(None), args.steps) if do_filip else None
+
+    clip_bg, filip_bg = clip_bl * world, filip_bl * world
+    pairs = (clip_bg if do_clip else 0) + (filip_bg if do_filip else 0)
+
+    # algorithmic work of the dominant kernel (FILIP score kernel), this rank's launch:
+    # 2 * d * (valid A tokens of the rank) * (valid B tokens of the global batch)
+    if do_filip:
+        nA = int(cpu["lA"].sum())
+        nB_local = torch.tensor([float(cpu["lB"].sum())], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(nB_local)
+        flops = 2.0 * D * nA * nB_local.item()
+        achieved = flops / (sim_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "filip_sim_traffic.json")
+        if world == 1 and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        roof = {"bound": "mfma", "kernel": "filip_sim_kernel", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "kernel_ms": sim_ms, "algorithmic_flops_per_launch": flops}
+    else:
+        # CLIP alone: 16*B*d algorithmic bytes per step over the whole step time (HBM roof)
+        byts = 16.0 * clip_bl * D + (8.0 * clip_bg * D if world > 1 else 0.0)
+        ach = byts / (t_clip / args.steps) / 1e9
+        roof = {"bound": "hbm", "kernel": "clip step (all kernels)", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ach / PEAK_HBM_GBS, "traffic": None}
+
+    if rank == 0:
+        workloads = {}
+        if do_clip:
+            ms = t_clip / args.steps * 1e3
+            flop = 6.0 * clip_bl * clip_bg * D
+            byts = 16.0 * clip_bl * D + (8.0 * clip_bg * D if world > 1 else 0.0)
+            workloads["clip"] = {
+                "global_batch": clip_bg, "per_gpu_batch": clip_bl, "d": D, "dtype": "f32", "ms_per_step": ms,
+                "pairs_per_s": clip_bg / (ms * 1e-3),
+                "algorithmic_bytes_per_gpu": byts, "algorithmic_flops_per_gpu": flop,
+                "hbm_GBs": byts / (ms * 1e-3) / 1e9, "hbm_frac": byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "f32_mfma_TFLOPs": flop / (ms * 1e-3) / 1e12, "f32_mfma_frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            }
+        if do_filip:
+            ms = t_filip / args.steps * 1e3
+            workloads["filip"] = {
+                "global_batch": filip_bg, "per_gpu_batch": filip_bl, "L": L, "d": D, "dtype": "bf16 operands, f32 accumulate",
+                "ms_per_step": ms, "pairs_per_s": filip_bg / (ms * 1e-3), "scored_pairs_per_s": filip_bl * filip_bg * world / (ms * 1e-3),
+                "sim_kernel_ms": sim_ms, "sim_kernel_TFLOPs": roof["achieved"], "sim_kernel_mfma_frac": roof["frac"],
+            }
+        out = {
+            "metric": "protein_pairs_per_sec", "value": pairs / (total / args.steps), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": total / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if do_filip else "f32", "data": "synthetic",
+            "config": {
+                "workload": {"both": f"clip_b{clip_bg}_d{D}+filip_b{filip_bg}_l{L}_d{D}", "clip": f"clip_b{clip_bg}_d{D}",
+                             "filip": f"filip_b{filip_bg}_l{L}_d{D}"}[args.workload],
+                "clip_global_batch": clip_bg, "filip_global_batch": filip_bg, "seq_len": L, "d": D,
+                "parallelism": f"dp{world}", "step": "fwd+bwd from raw head outputs to their gradients, both workloads back to back",
+            },
+            "roofline": roof,
+            "workloads": workloads,
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "both":
+            out["cpu_baseline"] = cpu_baseline(cpu, clip_bl, filip_bl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,12 +123,13 @@ int pclip_rowce_bwd(const float* logits, const float* lse, int Br, int Bc, int r
  * The contraction runs on bf16 matrix cores with f32 accumulation.
  *
  * Step 1, prep: h [B,T,d] f32 -> hn [B,Tp,128] bf16 (Tp = T rounded up to 32; pad rows and
- * pad columns zero), optionally normalised per token and optionally negated (pass
- * negate = 1 for the A side when t < 0, so that max(x/t) = max(-x)/|t|); maskw [B,Tp/32]
+ * pad columns zero), optionally normalised per token, and negated when tsign (optional
+ * device scalar, NULL = never) is negative: pass the temperature for the A side, so that
+ * max(x/t) = max(-x)/|t| also holds for t < 0 without a host read of t; maskw [B,Tp/32]
  * u32 = the mask bits of each 32-token tile (bit r = token 32*tile + r; any nonzero mask
  * byte counts as valid, as .bool() does at models.py:323-324).
  * ------------------------------------------------------------------------------------- */
-int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, int normalise, int negate,
+int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, int normalise, const float* tsign,
                      uint16_t* hn, uint32_t* maskw, void* stream);
 
 /* Step 2, scores.  hnA [Br,TAp,128], hnB [Bc,TBp,128] bf16 from prep; inv_abs_t = 1/|t| as a
@@ -157,8 +158,8 @@ int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int
 
 /* Step 4, backward of prep: dn [B,Tp,128] f32 (padded layout) -> dh [B,T,d] f32 through the
  * normalise Jacobian (I - n n^T)/|h| when normalise = 1 (identity otherwise), sign flipped
- * when negate = 1.  When `accumulate` is nonzero dh += instead of dh =. */
-int pclip_filip_prep_bwd(const float* h, const float* dn, int B, int T, int d, int normalise, int negate,
+ * when tsign (as in prep) is negative.  When `accumulate` is nonzero dh += instead of dh =. */
+int pclip_filip_prep_bwd(const float* h, const float* dn, int B, int T, int d, int normalise, const float* tsign,
                          int accumulate, float* dh, void* stream);
 
 #ifdef __cplusplus

@@ -15,8 +15,9 @@
 // ---- prep: f32 [B,T,d] -> bf16 [B,Tp,128] (+ mask words) --------------------------------
 // One block per 32-token tile of one sequence; wave w converts tokens w, w+4, ...
 __global__ __launch_bounds__(256) void filip_prep_kernel(const float* __restrict__ h, const uint8_t* __restrict__ mask, int B, int T, int d,
-                                                         int Tp, int normalise, int negate, uint16_t* __restrict__ hn,
-                                                         uint32_t* __restrict__ maskw) {
+                                                         int Tp, int normalise, const float* __restrict__ tsign,
+                                                         uint16_t* __restrict__ hn, uint32_t* __restrict__ maskw) {
+    const bool negate = tsign && tsign[0] < 0.f;
     const int ntile = Tp >> 5;
     const int seq = blockIdx.x / ntile, tile = blockIdx.x - seq * ntile;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -56,7 +57,9 @@ __global__ __launch_bounds__(256) void filip_prep_kernel(const float* __restrict
 // Masked and padding tokens carry a zero dn (the score backward never touches them), so
 // their dh comes out zero without consulting the mask.
 __global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dn, int B, int T, int d,
-                                                             int Tp, int normalise, int negate, int accumulate, float* __restrict__ dh) {
+                                                             int Tp, int normalise, const float* __restrict__ tsign, int accumulate,
+                                                             float* __restrict__ dh) {
+    const bool negate = tsign && tsign[0] < 0.f;
     const int lane = threadIdx.x & 63;
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (size_t)B * T) return;
@@ -347,24 +350,24 @@ static int filip_dims_ok(const char* who, int B, int T, int d) {
     return PCLIP_OK;
 }
 
-extern "C" int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, int normalise, int negate, uint16_t* hn,
+extern "C" int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, int normalise, const float* tsign, uint16_t* hn,
                                 uint32_t* maskw, void* stream) {
     PCLIP_REQUIRE(h && mask && hn && maskw, "filip_prep: null pointer");
     if (int rc = filip_dims_ok("filip_prep", B, T, d)) return rc;
     const int Tp = (T + 31) / 32 * 32;
-    hipLaunchKernelGGL(filip_prep_kernel, dim3(B * (Tp / 32)), dim3(256), 0, (hipStream_t)stream, h, mask, B, T, d, Tp, normalise, negate, hn,
+    hipLaunchKernelGGL(filip_prep_kernel, dim3(B * (Tp / 32)), dim3(256), 0, (hipStream_t)stream, h, mask, B, T, d, Tp, normalise, tsign, hn,
                        maskw);
     return pclip_check_launch("filip_prep_kernel");
 }
 
-extern "C" int pclip_filip_prep_bwd(const float* h, const float* dn, int B, int T, int d, int normalise, int negate, int accumulate, float* dh,
-                                    void* stream) {
+extern "C" int pclip_filip_prep_bwd(const float* h, const float* dn, int B, int T, int d, int normalise, const float* tsign, int accumulate,
+                                    float* dh, void* stream) {
     PCLIP_REQUIRE(h && dn && dh, "filip_prep_bwd: null pointer");
     if (int rc = filip_dims_ok("filip_prep_bwd", B, T, d)) return rc;
     const int Tp = (T + 31) / 32 * 32;
     const size_t rows = (size_t)B * T;
     hipLaunchKernelGGL(filip_prep_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, dn, B, T, d, Tp, normalise,
-                       negate, accumulate, dh);
+                       tsign, accumulate, dh);
     return pclip_check_launch("filip_prep_bwd_kernel");
 }
 

@@ -169,9 +169,10 @@ def _tp(T: int) -> int:
     return (T + 31) // 32 * 32
 
 
-def filip_prep(h, mask, normalise: bool, negate: bool = False):
+def filip_prep(h, mask, normalise: bool, tsign=None):
     """h [B,T,d] f32, mask [B,T] (any integer/bool dtype) -> (hn [B,Tp,128] bf16 bits as int16,
-    maskw [B,Tp/32] int32)."""
+    maskw [B,Tp/32] int32).  ``tsign``: optional device scalar; the image is negated when it
+    is negative (pass the temperature on the A side)."""
     require_gpu_tensor(h, F32, "h")
     B, T, d = h.shape
     m8 = (mask != 0).to(torch.uint8).contiguous()
@@ -180,7 +181,8 @@ def filip_prep(h, mask, normalise: bool, negate: bool = False):
     Tp = _tp(T)
     hn = torch.empty(B, Tp, 128, dtype=torch.int16, device=h.device)
     mw = torch.empty(B, Tp // 32, dtype=torch.int32, device=h.device)
-    check(_lib.load().pclip_filip_prep(ptr(h), ptr(m8), B, T, d, int(normalise), int(negate), ptr(hn), ptr(mw), stream_of(h)),
+    ts = None if tsign is None else _scalar(tsign, h.device, "tsign")
+    check(_lib.load().pclip_filip_prep(ptr(h), ptr(m8), B, T, d, int(normalise), ptr(ts), ptr(hn), ptr(mw), stream_of(h)),
           "pclip_filip_prep")
     return hn, mw
 
@@ -214,12 +216,63 @@ def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB,
     return dnA, dnB, dt
 
 
-def filip_prep_bwd(h, dn, normalise: bool, negate: bool = False, out: Optional[torch.Tensor] = None):
+def filip_prep_bwd(h, dn, normalise: bool, tsign=None, out: Optional[torch.Tensor] = None):
     require_gpu_tensor(h, F32, "h")
     require_gpu_tensor(dn, F32, "dn")
     B, T, d = h.shape
     acc = out is not None
     dh = out if acc else torch.empty_like(h)
-    check(_lib.load().pclip_filip_prep_bwd(ptr(h), ptr(dn), B, T, d, int(normalise), int(negate), int(acc), ptr(dh), stream_of(h)),
+    ts = None if tsign is None else _scalar(tsign, h.device, "tsign")
+    check(_lib.load().pclip_filip_prep_bwd(ptr(h), ptr(dn), B, T, d, int(normalise), ptr(ts), int(acc), ptr(dh), stream_of(h)),
           "pclip_filip_prep_bwd")
     return dh
+
+
+class FilipStep:
+    """Pre-allocated FILIP hot-path step for one shape: raw token embeddings -> normalise ->
+    scores -> both row InfoNCE losses -> every gradient.  ``run`` only enqueues kernels on the
+    current stream (12 C calls); ``sim_events`` optionally brackets the score kernel with the
+    two given ``torch.cuda.Event``s so its duration can be read after a sync."""
+
+    def __init__(self, Br: int, Bc: int, TA: int, TB: int, d: int, device, row_offset: int = 0, Bg=None):
+        dev = torch.device(device)
+        self.shape = (Br, Bc, TA, TB, d)
+        self.row_offset, self.Bg = row_offset, (Bc if Bg is None else Bg)
+        TAp, TBp = _tp(TA), _tp(TB)
+        e = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        self.hnA, self.mwA = e(Br, TAp, 128, dt=torch.int16), e(Br, TAp // 32, dt=torch.int32)
+        self.hnB, self.mwB = e(Bc, TBp, 128, dt=torch.int16), e(Bc, TBp // 32, dt=torch.int32)
+        self.simA, self.simB = e(Br, Bc), e(Br, Bc)
+        self.argA, self.argB = e(Br, Bc, TAp, dt=torch.int16), e(Br, Bc, TBp, dt=torch.int16)
+        self.lseA, self.lseB, self.lossA, self.lossB = e(Br), e(Br), e(1), e(1)
+        self.gA, self.gB = e(Br, Bc), e(Br, Bc)
+        self.dnA, self.dnB = e(Br, TAp, 128), e(Bc, TBp, 128)
+        self.dhA, self.dhB = e(Br, TA, d), e(Bc, TB, d)
+        self.dt = e(1)
+
+    def run(self, hA, hB, mA8, mB8, t, sim_events=None):
+        """hA [Br,TA,d], hB [Bc,TB,d] f32; mA8/mB8 uint8 masks; t 1-element f32 tensor (all on
+        the GPU).  Returns (lossA, lossB, dhA, dhB, dt); the loss is (lossA + lossB) / 2."""
+        lib = _lib.load()
+        Br, Bc, TA, TB, d = self.shape
+        st = stream_of(hA)
+        off, Bg = self.row_offset, self.Bg
+        check(lib.pclip_filip_prep(ptr(hA), ptr(mA8), Br, TA, d, 1, ptr(t), ptr(self.hnA), ptr(self.mwA), st), "pclip_filip_prep")
+        check(lib.pclip_filip_prep(ptr(hB), ptr(mB8), Bc, TB, d, 1, None, ptr(self.hnB), ptr(self.mwB), st), "pclip_filip_prep")
+        if sim_events is not None:
+            sim_events[0].record()
+        check(lib.pclip_filip_sim_fwd(ptr(self.hnA), ptr(self.mwA), Br, TA, ptr(self.hnB), ptr(self.mwB), Bc, TB, ptr(t), ptr(self.simA),
+                                      ptr(self.simB), ptr(self.argA), ptr(self.argB), st), "pclip_filip_sim_fwd")
+        if sim_events is not None:
+            sim_events[1].record()
+        check(lib.pclip_rowce_fwd(ptr(self.simA), Br, Bc, off, Bg, 0, ptr(self.lseA), ptr(self.lossA), st), "pclip_rowce_fwd")
+        check(lib.pclip_rowce_fwd(ptr(self.simB), Br, Bc, off, Bg, 0, ptr(self.lseB), ptr(self.lossB), st), "pclip_rowce_fwd")
+        check(lib.pclip_rowce_bwd(ptr(self.simA), ptr(self.lseA), Br, Bc, off, Bg, 0, None, 0.5, ptr(self.gA), st), "pclip_rowce_bwd")
+        check(lib.pclip_rowce_bwd(ptr(self.simB), ptr(self.lseB), Br, Bc, off, Bg, 0, None, 0.5, ptr(self.gB), st), "pclip_rowce_bwd")
+        self.dt.zero_()
+        check(lib.pclip_filip_sim_bwd(ptr(self.hnA), ptr(self.mwA), Br, TA, ptr(self.hnB), ptr(self.mwB), Bc, TB, ptr(t), ptr(self.simA),
+                                      ptr(self.simB), ptr(self.argA), ptr(self.argB), ptr(self.gA), ptr(self.gB), ptr(self.dnA),
+                                      ptr(self.dnB), ptr(self.dt), st), "pclip_filip_sim_bwd")
+        check(lib.pclip_filip_prep_bwd(ptr(hA), ptr(self.dnA), Br, TA, d, 1, ptr(t), 0, ptr(self.dhA), st), "pclip_filip_prep_bwd")
+        check(lib.pclip_filip_prep_bwd(ptr(hB), ptr(self.dnB), Bc, TB, d, 1, None, 0, ptr(self.dhB), st), "pclip_filip_prep_bwd")
+        return self.lossA, self.lossB, self.dhA, self.dhB, self.dt

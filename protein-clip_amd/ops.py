@@ -1,0 +1,201 @@
+"""Autograd operators over the HIP kernels, single-GPU and sharded (one process per GPU,
+``torch.distributed`` over RCCL).
+
+The sharded forms replace GradCache's sub-batch accumulation
+(modules/training_utils.py:92-155 in the reference): every rank encodes its own rows, the
+embeddings are all-gathered, each rank scores its row block of the global similarity matrix
+and produces gradients for its own rows only, so the result equals the single-device
+global-batch loss.
+
+All compute goes through a *kernel provider* (default: :mod:`protein_clip_amd.kernels`, the
+ctypes binding of libpclip.so).  There is no CPU implementation in this package; CPU
+tensors are rejected by the provider.  The provider argument exists so the communication
+logic can be exercised on CPU by tests that bring their own stand-in.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import kernels as _hip_kernels
+
+
+def _world(group):
+    if group is None and not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def _all_gather_rows(t: torch.Tensor, group, world: int) -> torch.Tensor:
+    """[n, ...] on every rank -> [world*n, ...], rank-major (rank r's rows at r*n)."""
+    if world == 1:
+        return t
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# L2 normalise + temperature scale   (modules/models.py:50-51)
+# --------------------------------------------------------------------------------------
+class _L2NormScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e, t, K):
+        e = e.contiguous()
+        ctx.K = K
+        ctx.save_for_backward(e, t)
+        return K.l2norm_scale_fwd(e, t)
+
+    @staticmethod
+    def backward(ctx, dx):
+        e, t = ctx.saved_tensors
+        de, dt = ctx.K.l2norm_scale_bwd(e, t, dx.contiguous())
+        return de, dt.reshape(t.shape).to(t.dtype), None
+
+
+def l2norm_scale(e: torch.Tensor, temperature: torch.Tensor, kernels=None) -> torch.Tensor:
+    """``F.normalize(e, dim=-1) * torch.exp(temperature / 2)`` as one kernel each way."""
+    return _L2NormScale.apply(e, temperature, kernels or _hip_kernels)
+
+
+# --------------------------------------------------------------------------------------
+# CLIP symmetric InfoNCE   (modules/training_utils.py:85-89, :260-264)
+# --------------------------------------------------------------------------------------
+class _ClipLoss(torch.autograd.Function):
+    """loss(x_own, y_own) for the global batch formed by all ranks' rows."""
+
+    @staticmethod
+    def forward(ctx, x, y, group, K):
+        world, rank = _world(group)
+        x = x.contiguous()
+        y = y.contiguous()
+        Bl = x.shape[0]
+        x_all = _all_gather_rows(x, group, world)
+        y_all = _all_gather_rows(y, group, world)
+        off = rank * Bl
+        lse_r, lse_c, loss, _ = K.clip_fwd(x, y, x_all, y_all, off)
+        if world > 1:
+            # both log-sum-exp vectors travel in one collective: [2,Bl] per rank -> [world,2,Bl]
+            both = torch.stack([lse_r, lse_c])
+            gathered = torch.empty((world,) + tuple(both.shape), dtype=both.dtype, device=both.device)
+            dist.all_gather_into_tensor(gathered, both, group=group)
+            lse_r_all = gathered[:, 0].reshape(-1).contiguous()
+            lse_c_all = gathered[:, 1].reshape(-1).contiguous()
+            dist.all_reduce(loss, group=group)
+        else:
+            lse_r_all, lse_c_all = lse_r, lse_c
+        ctx.K, ctx.off = K, off
+        ctx.save_for_backward(x, y, x_all, y_all, lse_r_all, lse_c_all)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, x_all, y_all, lse_r_all, lse_c_all = ctx.saved_tensors
+        dX, dY = ctx.K.clip_bwd(x, y, x_all, y_all, lse_r_all, lse_c_all, ctx.off, g=g.reshape(1))
+        return dX, dY, None, None
+
+
+def clip_loss(x: torch.Tensor, y: torch.Tensor, group=None, kernels=None) -> torch.Tensor:
+    """Symmetric InfoNCE of ``S = X_all Y_all^T`` where X_all/Y_all are the rows of every rank
+    (just ``x``/``y`` without a process group).  Every rank returns the same global loss; its
+    backward yields gradients for the rank's own rows."""
+    if x.dim() != 2 or x.shape != y.shape:
+        raise ValueError(f"clip_loss: expected two [B,d] tensors of one shape, got {tuple(x.shape)} and {tuple(y.shape)}")
+    return _ClipLoss.apply(x, y, group, kernels or _hip_kernels)
+
+
+def clip_exp_logits(x: torch.Tensor, y: torch.Tensor, kernels=None) -> torch.Tensor:
+    """``exp(x @ y.T)`` — what ``get_logits`` returns (modules/training_utils.py:170-172)."""
+    K = kernels or _hip_kernels
+    x = x.detach().contiguous()
+    y = y.detach().contiguous()
+    return K.clip_fwd(x, y, x, y, 0, logits_mode=2)[3]
+
+
+# --------------------------------------------------------------------------------------
+# row-wise InfoNCE   (modules/training_utils_filip.py:4-23)
+# --------------------------------------------------------------------------------------
+class _RowCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, use_dcl, row_offset, Bg, group, K):
+        logits = logits.contiguous()
+        lse, loss = K.rowce_fwd(logits, row_offset, Bg, use_dcl)
+        world, _ = _world(group)
+        if world > 1:
+            dist.all_reduce(loss, group=group)
+        ctx.K, ctx.cfg = K, (use_dcl, row_offset, Bg)
+        ctx.save_for_backward(logits, lse)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, lse = ctx.saved_tensors
+        use_dcl, row_offset, Bg = ctx.cfg
+        return ctx.K.rowce_bwd(logits, lse, row_offset, Bg, use_dcl, g=g.reshape(1)), None, None, None, None, None
+
+
+def row_ce(logits: torch.Tensor, use_dcl: bool = False, row_offset: int = 0, global_batch: Optional[int] = None, group=None,
+           kernels=None) -> torch.Tensor:
+    """``mean_i(-log E_ii + log sum_j E_ij)`` over the global batch; ``logits`` holds this rank's
+    rows, whose targets sit at column ``i + row_offset``."""
+    if logits.dim() != 2:
+        raise ValueError("row_ce: expected a 2-d logits tensor")
+    Bg = logits.shape[0] if global_batch is None else global_batch
+    return _RowCE.apply(logits, bool(use_dcl), row_offset, Bg, group, kernels or _hip_kernels)
+
+
+# --------------------------------------------------------------------------------------
+# FILIP scores   (modules/models.py:238-239, :292-356)
+# --------------------------------------------------------------------------------------
+class _FilipSim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hA, hB, maskA, maskB, t, normalise, group, K):
+        world, rank = _world(group)
+        hA = hA.contiguous()
+        hB = hB.contiguous()
+        # the A image is negated on the device when t < 0 (max(x/t) = max(-x)/|t|): no host read of t
+        hnA, mwA = K.filip_prep(hA, maskA, normalise, tsign=t)
+        hnB, mwB = K.filip_prep(hB, maskB, normalise)
+        hnB_all = _all_gather_rows(hnB, group, world)
+        mwB_all = _all_gather_rows(mwB, group, world)
+        TA, TB = hA.shape[1], hB.shape[1]
+        simA, simB, argA, argB = K.filip_sim_fwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, want_arg=True)
+        ctx.K, ctx.cfg = K, (normalise, TA, TB, group, world, rank)
+        ctx.save_for_backward(hA, hB, hnA, mwA, hnB_all, mwB_all, t, simA, simB, argA, argB)
+        ctx.mark_non_differentiable(argA, argB)
+        return simA, simB, argA, argB
+
+    @staticmethod
+    def backward(ctx, gA, gB, _ga, _gb):
+        hA, hB, hnA, mwA, hnB_all, mwB_all, t, simA, simB, argA, argB = ctx.saved_tensors
+        normalise, TA, TB, group, world, rank = ctx.cfg
+        K = ctx.K
+        dnA, dnB_all, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA.contiguous(),
+                                          gB.contiguous())
+        if world > 1:
+            # every rank holds a partial gradient for every B sequence: sum and hand each rank its own
+            dnB = torch.empty((hB.shape[0],) + tuple(dnB_all.shape[1:]), dtype=dnB_all.dtype, device=dnB_all.device)
+            dist.reduce_scatter_tensor(dnB, dnB_all, group=group)
+            dist.all_reduce(dt, group=group)
+        else:
+            dnB = dnB_all
+        dhA = K.filip_prep_bwd(hA, dnA, normalise, tsign=t)
+        dhB = K.filip_prep_bwd(hB, dnB, normalise)
+        return dhA, dhB, None, None, dt.reshape(t.shape).to(t.dtype), None, None, None
+
+
+def filip_similarity(hA, hB, maskA, maskB, temperature, normalise: bool = False, group=None, kernels=None):
+    """Token-wise max-similarity scores ``(sim_A, sim_B)``, each ``[B_own, B_global]``.
+
+    ``hA`` are this rank's A sequences, ``hB`` this rank's B sequences (gathered over the
+    group inside).  With ``normalise=True`` the per-token L2 normalisation of
+    ``ExtendedFILIP.forward`` (no epsilon) is fused into the operand preparation."""
+    if hA.dim() != 3 or hB.dim() != 3 or hA.shape[2] != hB.shape[2]:
+        raise ValueError("filip_similarity: expected hA [B,TA,d] and hB [B,TB,d] with one d")
+    if tuple(maskA.shape) != tuple(hA.shape[:2]) or tuple(maskB.shape) != tuple(hB.shape[:2]):
+        raise ValueError("filip_similarity: masks must be [B,T] matching the embeddings")
+    t = temperature if isinstance(temperature, torch.Tensor) else torch.tensor(float(temperature), device=hA.device)
+    simA, simB, _, _ = _FilipSim.apply(hA, hB, maskA, maskB, t, bool(normalise), group, kernels or _hip_kernels)
+    return simA, simB

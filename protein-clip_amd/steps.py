@@ -1,0 +1,116 @@
+"""Explicit forward+backward steps of the two hot paths, single-GPU or sharded over a
+process group (one process per GPU, RCCL), without autograd in the way.  These are what
+``bench.py`` times and what a trainer that manages its own gradients would call.
+
+CLIP (replaces GradCache's accumulation, modules/training_utils.py:117-153): every rank
+normalises its own rows, ONE all-gather moves both towers' embeddings, the rank scores its
+row block and its column block of the global logits, ONE all-gather moves the two
+log-sum-exp vectors, the backward produces gradients for the rank's own rows only (no
+gradient all-reduce of embeddings), ONE all-reduce sums {loss, dt}.
+
+FILIP (modules/models.py:221-245 + modules/training_utils_filip.py:26-39): both losses are
+row-wise, so a rank that owns A rows needs every B sequence: all-gather of the bf16 token
+images (+ mask words), local scores / losses / dA, reduce-scatter of dB, one all-reduce of
+{loss_A, loss_B, dt}.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import kernels as _hip_kernels
+
+
+def _world(group):
+    if group is None and not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def _gather(t, group, world):
+    if world == 1:
+        return t
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
+class ClipShardedStep:
+    def __init__(self, group=None, kernels=None):
+        self.group, self.K = group, kernels or _hip_kernels
+        self.world, self.rank = _world(group)
+
+    def run(self, e_pep, e_rec, t):
+        """e_pep/e_rec [Bl,d] f32: this rank's raw head outputs; t: 1-element f32 tensor.
+        Returns (loss, d e_pep, d e_rec, dt) — loss and dt are global (identical on all ranks)."""
+        K, W = self.K, self.world
+        Bl, d = e_pep.shape
+        x = K.l2norm_scale_fwd(e_pep, t)
+        y = K.l2norm_scale_fwd(e_rec, t)
+        if W > 1:
+            both = _gather(torch.stack([x, y]), self.group, W)       # [W,2,Bl,d]
+            x_all = both[:, 0].reshape(W * Bl, d).contiguous()
+            y_all = both[:, 1].reshape(W * Bl, d).contiguous()
+        else:
+            x_all, y_all = x, y
+        off = self.rank * Bl
+        lse_r, lse_c, loss, _ = K.clip_fwd(x, y, x_all, y_all, off)
+        if W > 1:
+            lse = _gather(torch.stack([lse_r, lse_c]), self.group, W)  # [W,2,Bl]
+            lse_r_all = lse[:, 0].reshape(-1).contiguous()
+            lse_c_all = lse[:, 1].reshape(-1).contiguous()
+        else:
+            lse_r_all, lse_c_all = lse_r, lse_c
+        dX, dY = K.clip_bwd(x, y, x_all, y_all, lse_r_all, lse_c_all, off)
+        de_pep, dt = K.l2norm_scale_bwd(e_pep, t, dX)
+        de_rec, dt = K.l2norm_scale_bwd(e_rec, t, dY, dt=dt)
+        if W > 1:
+            pack = torch.cat([loss.reshape(1), dt.reshape(1)])
+            dist.all_reduce(pack, group=self.group)
+            loss, dt = pack[0:1], pack[1:2]
+        return loss, de_pep, de_rec, dt
+
+
+class FilipShardedStep:
+    def __init__(self, group=None, kernels=None):
+        self.group, self.K = group, kernels or _hip_kernels
+        self.world, self.rank = _world(group)
+        self.last = {}
+
+    def run(self, hA, hB, maskA, maskB, t, sim_events=None):
+        """hA [Bl,TA,d], hB [Bl,TB,d] f32 raw token embeddings of this rank's pairs; masks
+        [Bl,T]; t 1-element f32 tensor.  Returns (loss, d hA, d hB, dt)."""
+        K, W = self.K, self.world
+        Bl, TA, TB = hA.shape[0], hA.shape[1], hB.shape[1]
+        Bg = W * Bl
+        hnA, mwA = K.filip_prep(hA, maskA, True, tsign=t)
+        hnB, mwB = K.filip_prep(hB, maskB, True)
+        if W > 1:
+            hnB_all = _gather(hnB, self.group, W).reshape((Bg,) + tuple(hnB.shape[1:]))
+            mwB_all = _gather(mwB, self.group, W).reshape((Bg,) + tuple(mwB.shape[1:]))
+        else:
+            hnB_all, mwB_all = hnB, mwB
+        if sim_events is not None:
+            sim_events[0].record()
+        simA, simB, argA, argB = K.filip_sim_fwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, want_arg=True)
+        if sim_events is not None:
+            sim_events[1].record()
+        off = self.rank * Bl
+        lseA, lossA = K.rowce_fwd(simA, off, Bg, False)
+        lseB, lossB = K.rowce_fwd(simB, off, Bg, False)
+        gA = K.rowce_bwd(simA, lseA, off, Bg, False, gscale=0.5)
+        gB = K.rowce_bwd(simB, lseB, off, Bg, False, gscale=0.5)
+        dnA, dnB_all, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB)
+        if W > 1:
+            dnB = torch.empty((Bl,) + tuple(dnB_all.shape[1:]), dtype=dnB_all.dtype, device=dnB_all.device)
+            dist.reduce_scatter_tensor(dnB, dnB_all, group=self.group)
+        else:
+            dnB = dnB_all
+        dhA = K.filip_prep_bwd(hA, dnA, True, tsign=t)
+        dhB = K.filip_prep_bwd(hB, dnB, True)
+        pack = torch.cat([lossA.reshape(1), lossB.reshape(1), dt.reshape(1)])
+        if W > 1:
+            dist.all_reduce(pack, group=self.group)
+        loss = (pack[0:1] + pack[1:2]) * 0.5
+        self.last = {"simA": simA, "simB": simB}
+        return loss, dhA, dhB, pack[2:3]

@@ -178,8 +178,7 @@ def test_rowce_uniform_logits_give_log_B(K):
 # FILIP
 # ------------------------------------------------------------------------------------------
 def _filip_fwd(K, hA, hB, mA, mB, t, normalise):
-    neg = bool(t < 0)
-    hnA, mwA = K.filip_prep(dev(hA), dev(mA), normalise, negate=neg)
+    hnA, mwA = K.filip_prep(dev(hA), dev(mA), normalise, tsign=dev(t.reshape(1)))
     hnB, mwB = K.filip_prep(dev(hB), dev(mB), normalise)
     out = K.filip_sim_fwd(hnA, mwA, hA.shape[1], hnB, mwB, hB.shape[1], dev(t.reshape(1)))
     return (hnA, mwA, hnB, mwB) + out
@@ -259,7 +258,7 @@ def test_filip_backward_matches_oracle(K, filip_cases):
         close(simB, sB, 2e-6, 2e-6)
         dnA, dnB, dt = K.filip_sim_bwd(hnA, mwA, hA.shape[1], hnB, mwB, hB.shape[1], dev(t.reshape(1)), simA, simB, argA, argB,
                                        dev(gA), dev(gB))
-        dA = K.filip_prep_bwd(dev(hA), dnA, normalise=not pre)
+        dA = K.filip_prep_bwd(dev(hA), dnA, normalise=not pre, tsign=dev(t.reshape(1)))
         dB = K.filip_prep_bwd(dev(hB), dnB, normalise=not pre)
         mostly_close(dA, dA_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)
         mostly_close(dB, dB_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)

@@ -148,13 +148,17 @@ int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int
  * the max routes each gradient to its arg-max partner).  gA, gB [Br,Bc] f32 = d loss / d sim_A,
  * d loss / d sim_B.  Outputs (f32, OVERWRITTEN): dnA [Br,TA,128p] and dnB [Bc,TB,128p] hold
  * d loss / d (normalised operand) in the padded [.,Tp,128] layout of prep; dt is
- * ACCUMULATED: dt += -(1/t) * sum(gA*sim_A + gB*sim_B). */
+ * ACCUMULATED: dt += -(1/t) * sum(gA*sim_A + gB*sim_B).  `ws` holds the bucketed token lists
+ * (sized by pclip_filip_bwd_workspace_bytes; about 4*Br*Bc*(TAp+TBp) bytes).  The order in
+ * which a row's contributions are summed is not fixed, so results may differ in the last
+ * bits from run to run. */
+size_t pclip_filip_bwd_workspace_bytes(int Br, int TA, int Bc, int TB);
 int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
                         const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,
                         const float* t, const float* sim_A, const float* sim_B,
                         const uint16_t* argA, const uint16_t* argB,
                         const float* gA, const float* gB,
-                        float* dnA, float* dnB, float* dt, void* stream);
+                        float* dnA, float* dnB, float* dt, void* ws, size_t ws_bytes, void* stream);
 
 /* Step 4, backward of prep: dn [B,Tp,128] f32 (padded layout) -> dh [B,T,d] f32 through the
  * normalise Jacobian (I - n n^T)/|h| when normalise = 1 (identity otherwise), sign flipped

@@ -263,86 +263,6 @@ __global__ __launch_bounds__(256, 2) void filip_sim_kernel(FilipArgs p) {
     }
 }
 
-// ---- backward of the scores: arg-max routed gather/scatter ---------------------------------
-// One workgroup owns one "own" sequence and keeps its whole [Tp][128] f32 gradient in LDS;
-// it walks every partner sequence, and for each pair adds
-//   own[a]       += w1 * partner[arg1[a]]      (own-side max terms)
-//   own[arg2[b]] += w2 * partner[b]            (partner-side max terms that chose a)
-// with LDS float atomics.  16 lanes move one 256-B bf16 row.
-struct FilipBwdArgs {
-    const uint16_t* hnP;   // partner images [Np][TPp][128]
-    const uint32_t* mwO;   // own mask words [No][ntO]
-    const uint32_t* mwP;   // partner mask words
-    int No, TOp, Np, TPp;
-    const uint16_t* arg1;  // [pair][TOp]  partner token chosen by each own token
-    const uint16_t* arg2;  // [pair][TPp]  own token chosen by each partner token
-    const float* g1;       // d loss / d sim of the own-side score, [pair]
-    const float* g2;       // d loss / d sim of the partner-side score, [pair]
-    size_t so, sp;         // pair index = own*so + partner*sp
-    const float* t;
-    float* dn;             // [No][TOp][128] f32 out
-};
-
-__global__ __launch_bounds__(256) void filip_bwd_kernel(FilipBwdArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* acc = reinterpret_cast<float*>(smem);  // [TOp][128]
-    const int tid = threadIdx.x;
-    const int o = blockIdx.x;
-    const int ntO = p.TOp >> 5, ntP = p.TPp >> 5;
-    for (int k = tid; k < p.TOp * FD; k += 256) acc[k] = 0.f;
-    int nO = 0;
-    for (int tt = 0; tt < ntO; ++tt) nO += __popc(p.mwO[(size_t)o * ntO + tt]);
-    const float inv_t = 1.f / fabsf(p.t[0]);
-    const int grp = tid >> 4, l16 = tid & 15;  // 16 row groups of 16 lanes
-    __syncthreads();
-    for (int q = 0; q < p.Np; ++q) {
-        const size_t pair = (size_t)o * p.so + (size_t)q * p.sp;
-        int nP = 0;
-        for (int tt = 0; tt < ntP; ++tt) nP += __popc(p.mwP[(size_t)q * ntP + tt]);
-        const float w1 = p.g1[pair] / fmaxf((float)nO, 1e-6f) * inv_t;
-        const float w2 = p.g2[pair] / fmaxf((float)nP, 1e-6f) * inv_t;
-        const uint16_t* a1 = p.arg1 + pair * p.TOp;
-        const uint16_t* a2 = p.arg2 + pair * p.TPp;
-        const uint16_t* img = p.hnP + (size_t)q * p.TPp * FD;
-        if (nP > 0) {
-            for (int a = grp; a < p.TOp; a += 16) {
-                if (!((p.mwO[(size_t)o * ntO + (a >> 5)] >> (a & 31)) & 1u)) continue;
-                const int b = a1[a];
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(img + (size_t)b * FD + l16 * 8);
-                float* dst = acc + a * FD + l16 * 8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) atomicAdd(dst + e, w1 * (float)v[e]);
-            }
-        }
-        if (nO > 0) {
-            for (int b = grp; b < p.TPp; b += 16) {
-                if (!((p.mwP[(size_t)q * ntP + (b >> 5)] >> (b & 31)) & 1u)) continue;
-                const int a = a2[b];
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(img + (size_t)b * FD + l16 * 8);
-                float* dst = acc + a * FD + l16 * 8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) atomicAdd(dst + e, w2 * (float)v[e]);
-            }
-        }
-    }
-    __syncthreads();
-    float* out = p.dn + (size_t)o * p.TOp * FD;
-    for (int k = tid; k < p.TOp * FD; k += 256) out[k] = acc[k];
-}
-
-// dt += -(1/t) * sum(gA*simA + gB*simB)
-__global__ __launch_bounds__(256) void filip_dt_kernel(const float* __restrict__ gA, const float* __restrict__ gB, const float* __restrict__ sA,
-                                                       const float* __restrict__ sB, size_t n, const float* __restrict__ t,
-                                                       float* __restrict__ dt) {
-    __shared__ float red[4];
-    float acc = 0.f;
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) acc += gA[k] * sA[k] + gB[k] * sB[k];
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dt, -(red[0] + red[1] + red[2] + red[3]) / t[0]);
-}
-
 // ---- host side -------------------------------------------------------------------------
 static int filip_dims_ok(const char* who, int B, int T, int d) {
     PCLIP_REQUIRE(B >= 1 && T >= 1 && T <= PCLIP_FILIP_MAX_T, "%s: B=%d T=%d (need 1 <= T <= %d)", who, B, T, PCLIP_FILIP_MAX_T);
@@ -396,36 +316,4 @@ extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, 
     }
     hipLaunchKernelGGL(filip_sim_kernel, dim3(Br * nchunk), dim3(256), LDS_TOTAL, (hipStream_t)stream, a);
     return pclip_check_launch("filip_sim_kernel");
-}
-
-extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
-                                   int Bc, int TB, const float* t, const float* sim_A, const float* sim_B, const uint16_t* argA,
-                                   const uint16_t* argB, const float* gA, const float* gB, float* dnA, float* dnB, float* dt, void* stream) {
-    PCLIP_REQUIRE(hnA && maskwA && hnB && maskwB && t && sim_A && sim_B && argA && argB && gA && gB && dnA && dnB && dt,
-                  "filip_sim_bwd: null pointer");
-    if (int rc = filip_dims_ok("filip_sim_bwd", Br, TA, FD)) return rc;
-    if (int rc = filip_dims_ok("filip_sim_bwd", Bc, TB, FD)) return rc;
-    const int TAp = (TA + 31) / 32 * 32, TBp = (TB + 31) / 32 * 32;
-    hipStream_t st = (hipStream_t)stream;
-    static bool lds_set = false;
-    if (!lds_set) {
-        if (hipFuncSetAttribute((const void*)filip_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * FD * 4) != hipSuccess)
-            return pclip_fail(PCLIP_ELAUNCH, "filip_bwd_kernel: cannot raise the dynamic LDS limit");
-        lds_set = true;
-    }
-    FilipBwdArgs a;
-    // d/d A images: own = A(i), partner = B(j), pair = i*Bc + j
-    a.hnP = hnB; a.mwO = maskwA; a.mwP = maskwB; a.No = Br; a.TOp = TAp; a.Np = Bc; a.TPp = TBp;
-    a.arg1 = argA; a.arg2 = argB; a.g1 = gA; a.g2 = gB; a.so = (size_t)Bc; a.sp = 1; a.t = t; a.dn = dnA;
-    hipLaunchKernelGGL(filip_bwd_kernel, dim3(Br), dim3(256), (size_t)TAp * FD * 4, st, a);
-    if (int rc = pclip_check_launch("filip_bwd_kernel(A)")) return rc;
-    // d/d B images: own = B(j), partner = A(i), pair = i*Bc + j
-    a.hnP = hnA; a.mwO = maskwB; a.mwP = maskwA; a.No = Bc; a.TOp = TBp; a.Np = Br; a.TPp = TAp;
-    a.arg1 = argB; a.arg2 = argA; a.g1 = gB; a.g2 = gA; a.so = 1; a.sp = (size_t)Bc; a.dn = dnB;
-    hipLaunchKernelGGL(filip_bwd_kernel, dim3(Bc), dim3(256), (size_t)TBp * FD * 4, st, a);
-    if (int rc = pclip_check_launch("filip_bwd_kernel(B)")) return rc;
-    const size_t n = (size_t)Br * Bc;
-    const int blocks = (int)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
-    hipLaunchKernelGGL(filip_dt_kernel, dim3(blocks), dim3(256), 0, st, gA, gB, sim_A, sim_B, n, t, dt);
-    return pclip_check_launch("filip_dt_kernel");
 }

@@ -210,9 +210,11 @@ def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB,
     dnB = torch.empty(Bc, _tp(TB), 128, dtype=F32, device=dev)
     if dt is None:
         dt = torch.zeros(1, dtype=F32, device=dev)
-    check(_lib.load().pclip_filip_sim_bwd(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), ptr(simA), ptr(simB),
-                                          ptr(argA), ptr(argB), ptr(gA), ptr(gB), ptr(dnA), ptr(dnB), ptr(dt), stream_of(hnA)),
-          "pclip_filip_sim_bwd")
+    lib = _lib.load()
+    ws = _workspace(dev, lib.pclip_filip_bwd_workspace_bytes(Br, TA, Bc, TB))
+    check(lib.pclip_filip_sim_bwd(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), ptr(simA), ptr(simB),
+                                  ptr(argA), ptr(argB), ptr(gA), ptr(gB), ptr(dnA), ptr(dnB), ptr(dt), ptr(ws), ws.numel(),
+                                  stream_of(hnA)), "pclip_filip_sim_bwd")
     return dnA, dnB, dt
 
 
@@ -249,6 +251,7 @@ class FilipStep:
         self.dnA, self.dnB = e(Br, TAp, 128), e(Bc, TBp, 128)
         self.dhA, self.dhB = e(Br, TA, d), e(Bc, TB, d)
         self.dt = e(1)
+        self.bws = e(_lib.load().pclip_filip_bwd_workspace_bytes(Br, TA, Bc, TB), dt=torch.uint8)
 
     def run(self, hA, hB, mA8, mB8, t, sim_events=None):
         """hA [Br,TA,d], hB [Bc,TB,d] f32; mA8/mB8 uint8 masks; t 1-element f32 tensor (all on
@@ -272,7 +275,7 @@ class FilipStep:
         self.dt.zero_()
         check(lib.pclip_filip_sim_bwd(ptr(self.hnA), ptr(self.mwA), Br, TA, ptr(self.hnB), ptr(self.mwB), Bc, TB, ptr(t), ptr(self.simA),
                                       ptr(self.simB), ptr(self.argA), ptr(self.argB), ptr(self.gA), ptr(self.gB), ptr(self.dnA),
-                                      ptr(self.dnB), ptr(self.dt), st), "pclip_filip_sim_bwd")
+                                      ptr(self.dnB), ptr(self.dt), ptr(self.bws), self.bws.numel(), st), "pclip_filip_sim_bwd")
         check(lib.pclip_filip_prep_bwd(ptr(hA), ptr(self.dnA), Br, TA, d, 1, ptr(t), 0, ptr(self.dhA), st), "pclip_filip_prep_bwd")
         check(lib.pclip_filip_prep_bwd(ptr(hB), ptr(self.dnB), Bc, TB, d, 1, None, 0, ptr(self.dhB), st), "pclip_filip_prep_bwd")
         return self.lossA, self.lossB, self.dhA, self.dhB, self.dt

@@ -132,8 +132,11 @@ int pclip_rowce_bwd(const float* logits, const float* lse, int Br, int Bc, int r
 int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, int normalise, const float* tsign,
                      uint16_t* hn, uint32_t* maskw, void* stream);
 
-/* Step 2, scores.  hnA [Br,TAp,128], hnB [Bc,TBp,128] bf16 from prep; inv_abs_t = 1/|t| as a
- * device scalar pointer `t` (the kernel reads t and uses 1/|t|).
+/* Step 2, scores.  hnA [Br,TAp,128], hnB [Bc,TBp,128] bf16 from prep; `t` is the temperature
+ * as a device scalar (the kernel uses 1/|t|; the sign was folded into hnA by prep).
+ * unit_norm != 0 asserts that every token row has L2 norm <= 1 (prep with normalise = 1):
+ * the kernel then keeps value and arg-max in one integer maximum per element (scores within
+ * 2e-6 of the exact maximum); unit_norm = 0 makes no assumption (exact f32 maxima, slower).
  *   sim_A, sim_B [Br,Bc] f32
  *   argA [Br,Bc,TAp] u16: for each a the b attaining the max (0 where a is padding)
  *   argB [Br,Bc,TBp] u16: for each b the a attaining the max
@@ -141,7 +144,7 @@ int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, i
  * TA, TB <= PCLIP_FILIP_MAX_T. */
 int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
                         const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,
-                        const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
+                        const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
                         void* stream);
 
 /* Step 3, backward of the scores w.r.t. the bf16 operands (autograd of models.py:332-351:

@@ -292,11 +292,15 @@ extern "C" int pclip_filip_prep_bwd(const float* h, const float* dn, int B, int 
 }
 
 extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
-                                   int Bc, int TB, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, void* stream) {
+                                   int Bc, int TB, const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
+                                   void* stream) {
     PCLIP_REQUIRE(hnA && maskwA && hnB && maskwB && t && sim_A && sim_B, "filip_sim_fwd: null pointer");
     PCLIP_REQUIRE((argA == nullptr) == (argB == nullptr), "filip_sim_fwd: pass both argA and argB or neither");
     if (int rc = filip_dims_ok("filip_sim_fwd", Br, TA, FD)) return rc;
     if (int rc = filip_dims_ok("filip_sim_fwd", Bc, TB, FD)) return rc;
+    if (unit_norm)
+        return filip_sim_unit_launch(hnA, maskwA, Br, (TA + 31) / 32 * 32, hnB, maskwB, Bc, (TB + 31) / 32 * 32, t, sim_A, sim_B, argA, argB,
+                                     stream);
     FilipArgs a;
     a.hnA = hnA; a.mwA = maskwA; a.Br = Br; a.TAp = (TA + 31) / 32 * 32;
     a.hnB = hnB; a.mwB = maskwB; a.Bc = Bc; a.TBp = (TB + 31) / 32 * 32;

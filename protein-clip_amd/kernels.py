@@ -187,7 +187,7 @@ def filip_prep(h, mask, normalise: bool, tsign=None):
     return hn, mw
 
 
-def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True):
+def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True, unit_norm: bool = False):
     dev = hnA.device
     Br, Bc = hnA.shape[0], hnB.shape[0]
     tt = _scalar(t, dev, "t")
@@ -195,8 +195,8 @@ def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True
     simB = torch.empty(Br, Bc, dtype=F32, device=dev)
     argA = torch.empty(Br, Bc, _tp(TA), dtype=torch.int16, device=dev) if want_arg else None
     argB = torch.empty(Br, Bc, _tp(TB), dtype=torch.int16, device=dev) if want_arg else None
-    check(_lib.load().pclip_filip_sim_fwd(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), ptr(simA), ptr(simB),
-                                          ptr(argA), ptr(argB), stream_of(hnA)), "pclip_filip_sim_fwd")
+    check(_lib.load().pclip_filip_sim_fwd(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), int(unit_norm), ptr(simA),
+                                          ptr(simB), ptr(argA), ptr(argB), stream_of(hnA)), "pclip_filip_sim_fwd")
     return simA, simB, argA, argB
 
 
@@ -264,7 +264,7 @@ class FilipStep:
         check(lib.pclip_filip_prep(ptr(hB), ptr(mB8), Bc, TB, d, 1, None, ptr(self.hnB), ptr(self.mwB), st), "pclip_filip_prep")
         if sim_events is not None:
             sim_events[0].record()
-        check(lib.pclip_filip_sim_fwd(ptr(self.hnA), ptr(self.mwA), Br, TA, ptr(self.hnB), ptr(self.mwB), Bc, TB, ptr(t), ptr(self.simA),
+        check(lib.pclip_filip_sim_fwd(ptr(self.hnA), ptr(self.mwA), Br, TA, ptr(self.hnB), ptr(self.mwB), Bc, TB, ptr(t), 1, ptr(self.simA),
                                       ptr(self.simB), ptr(self.argA), ptr(self.argB), st), "pclip_filip_sim_fwd")
         if sim_events is not None:
             sim_events[1].record()

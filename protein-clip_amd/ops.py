@@ -161,7 +161,7 @@ class _FilipSim(torch.autograd.Function):
         hnB_all = _all_gather_rows(hnB, group, world)
         mwB_all = _all_gather_rows(mwB, group, world)
         TA, TB = hA.shape[1], hB.shape[1]
-        simA, simB, argA, argB = K.filip_sim_fwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, want_arg=True)
+        simA, simB, argA, argB = K.filip_sim_fwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, want_arg=True, unit_norm=bool(normalise))
         ctx.K, ctx.cfg = K, (normalise, TA, TB, group, world, rank)
         ctx.save_for_backward(hA, hB, hnA, mwA, hnB_all, mwB_all, t, simA, simB, argA, argB)
         ctx.mark_non_differentiable(argA, argB)

@@ -92,7 +92,7 @@ class FilipShardedStep:
             hnB_all, mwB_all = hnB, mwB
         if sim_events is not None:
             sim_events[0].record()
-        simA, simB, argA, argB = K.filip_sim_fwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, want_arg=True)
+        simA, simB, argA, argB = K.filip_sim_fwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, want_arg=True, unit_norm=True)
         if sim_events is not None:
             sim_events[1].record()
         off = self.rank * Bl

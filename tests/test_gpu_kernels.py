@@ -177,10 +177,11 @@ def test_rowce_uniform_logits_give_log_B(K):
 # ------------------------------------------------------------------------------------------
 # FILIP
 # ------------------------------------------------------------------------------------------
-def _filip_fwd(K, hA, hB, mA, mB, t, normalise):
+def _filip_fwd(K, hA, hB, mA, mB, t, normalise, unit=None):
+    unit = normalise if unit is None else unit
     hnA, mwA = K.filip_prep(dev(hA), dev(mA), normalise, tsign=dev(t.reshape(1)))
     hnB, mwB = K.filip_prep(dev(hB), dev(mB), normalise)
-    out = K.filip_sim_fwd(hnA, mwA, hA.shape[1], hnB, mwB, hB.shape[1], dev(t.reshape(1)))
+    out = K.filip_sim_fwd(hnA, mwA, hA.shape[1], hnB, mwB, hB.shape[1], dev(t.reshape(1)), unit_norm=unit)
     return (hnA, mwA, hnB, mwB) + out
 
 

@@ -39,33 +39,48 @@ __global__ __launch_bounds__(256) void filip_count_kernel(const uint32_t* __rest
     ic[s] = c > 0 ? 1.f / (float)c : 0.f;
 }
 
-// One workgroup per own sequence: counting sort of the valid partner tokens by the own token
-// they chose.
-__global__ __launch_bounds__(256) void filip_invert_kernel(FilipBwdArgs p) {
-    __shared__ int hist[PCLIP_FILIP_MAX_T + 1];
-    __shared__ int cursor[PCLIP_FILIP_MAX_T];
+// One workgroup (16 waves) per own sequence: counting sort of the valid partner tokens by the
+// own token they chose.  Partners are cut into INV_NCH consecutive chunks and a bucket is laid
+// out chunk by chunk, so the gather kernel walks every bucket in (roughly) ascending partner
+// order — the same order in which all the other buckets walk — and the partner images it
+// touches at any moment stay in the XCD's L2.  Eight u16 entries are read per 16-byte load.
+#define INV_NCH 32
+__global__ __launch_bounds__(1024) void filip_invert_kernel(FilipBwdArgs p) {
+    __shared__ int hist[INV_NCH * PCLIP_FILIP_MAX_T];   // [chunk][own token] counts, then bucket cursors
+    __shared__ int tot[PCLIP_FILIP_MAX_T];
     const int tid = threadIdx.x;
     const int o = blockIdx.x;
     const int ntP = p.TPp >> 5;
+    const int vpr = p.TPp >> 3;                          // 8-entry vectors per partner row
+    const int qpc = (p.Np + INV_NCH - 1) / INV_NCH;      // partners per chunk
     int* seg = p.seg + (size_t)o * (p.TOp + 1);
-    for (int k = tid; k <= p.TOp; k += 256) hist[k] = 0;
+    for (int k = tid; k < INV_NCH * PCLIP_FILIP_MAX_T; k += 1024) hist[k] = 0;
     __syncthreads();
     const bool own_live = p.icO[o] > 0.f;
-    const int total = own_live ? p.Np * p.TPp : 0;
-    for (int e = tid; e < total; e += 256) {
-        const int q = e / p.TPp, pt = e - q * p.TPp;
-        if ((p.mwP[(size_t)q * ntP + (pt >> 5)] >> (pt & 31)) & 1u) {
-            const int a = p.arg2[((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt];
-            atomicAdd(&hist[a], 1);
-        }
+    const int nvec = own_live ? p.Np * vpr : 0;
+    for (int v = tid; v < nvec; v += 1024) {
+        const int q = v / vpr, pt0 = (v - q * vpr) * 8;
+        const uint32_t m8 = (p.mwP[(size_t)q * ntP + (pt0 >> 5)] >> (pt0 & 31)) & 0xffu;
+        if (m8 == 0) continue;
+        const uint4 d = *reinterpret_cast<const uint4*>(p.arg2 + ((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt0);
+        const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+        int* hc = hist + (q / qpc) * PCLIP_FILIP_MAX_T;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if ((m8 >> k) & 1u) atomicAdd(&hc[(dw[k >> 1] >> (16 * (k & 1))) & 0xffffu], 1);
     }
     __syncthreads();
-    if (tid < 64) {  // exclusive scan of up to 256 counts by one wave, 4 per lane
+    if (tid < PCLIP_FILIP_MAX_T) {
+        int s = 0;
+        for (int ch = 0; ch < INV_NCH; ++ch) s += hist[ch * PCLIP_FILIP_MAX_T + tid];
+        tot[tid] = tid < p.TOp ? s : 0;
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan of the 256 bucket sizes by one wave, 4 per lane
         int v[4], s = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int idx = tid * 4 + k;
-            v[k] = idx < p.TOp ? hist[idx] : 0;
+            v[k] = tot[tid * 4 + k];
             s += v[k];
         }
         int incl = s;
@@ -78,23 +93,36 @@ __global__ __launch_bounds__(256) void filip_invert_kernel(FilipBwdArgs p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int idx = tid * 4 + k;
-            if (idx < p.TOp) {
-                seg[idx] = run;
-                cursor[idx] = run;
-            }
+            tot[idx] = run;
+            if (idx < p.TOp) seg[idx] = run;
             run += v[k];
         }
         if (tid == 63) seg[p.TOp] = incl;
     }
     __syncthreads();
-    uint32_t* list = p.list + (size_t)o * p.Np * p.TPp;
-    for (int e = tid; e < total; e += 256) {
-        const int q = e / p.TPp, pt = e - q * p.TPp;
-        if ((p.mwP[(size_t)q * ntP + (pt >> 5)] >> (pt & 31)) & 1u) {
-            const int a = p.arg2[((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt];
-            const int pos = atomicAdd(&cursor[a], 1);
-            list[pos] = ((uint32_t)q << 16) | (uint32_t)pt;
+    if (tid < PCLIP_FILIP_MAX_T) {  // counts -> running cursors, chunk after chunk inside each bucket
+        int run = tot[tid];
+        for (int ch = 0; ch < INV_NCH; ++ch) {
+            const int n = hist[ch * PCLIP_FILIP_MAX_T + tid];
+            hist[ch * PCLIP_FILIP_MAX_T + tid] = run;
+            run += n;
         }
+    }
+    __syncthreads();
+    uint32_t* list = p.list + (size_t)o * p.Np * p.TPp;
+    for (int v = tid; v < nvec; v += 1024) {
+        const int q = v / vpr, pt0 = (v - q * vpr) * 8;
+        const uint32_t m8 = (p.mwP[(size_t)q * ntP + (pt0 >> 5)] >> (pt0 & 31)) & 0xffu;
+        if (m8 == 0) continue;
+        const uint4 d = *reinterpret_cast<const uint4*>(p.arg2 + ((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt0);
+        const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+        int* hc = hist + (q / qpc) * PCLIP_FILIP_MAX_T;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if ((m8 >> k) & 1u) {
+                const int pos = atomicAdd(&hc[(dw[k >> 1] >> (16 * (k & 1))) & 0xffffu], 1);
+                list[pos] = ((uint32_t)q << 16) | (uint32_t)(pt0 + k);
+            }
     }
 }
 
@@ -229,14 +257,14 @@ extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, 
     a.hnP = hnB; a.mwO = maskwA; a.mwP = maskwB; a.No = Br; a.TOp = TAp; a.Np = Bc; a.TPp = TBp;
     a.arg1 = argA; a.arg2 = argB; a.g1 = gA; a.g2 = gB; a.so = (size_t)Bc; a.sp = 1; a.t = t;
     a.icO = icA; a.icP = icB; a.seg = (int*)(w + L.segA); a.list = (uint32_t*)(w + L.listA); a.dn = dnA;
-    hipLaunchKernelGGL(filip_invert_kernel, dim3(Br), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(filip_invert_kernel, dim3(Br), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(filip_gather_kernel, dim3(Br * (TAp / 16)), dim3(256), 0, st, a);
     if (int rc = pclip_check_launch("filip backward (A side)")) return rc;
     // gradient of the B images: own = B(j), partner = A(i), pair = i*Bc + j
     a.hnP = hnA; a.mwO = maskwB; a.mwP = maskwA; a.No = Bc; a.TOp = TBp; a.Np = Br; a.TPp = TAp;
     a.arg1 = argB; a.arg2 = argA; a.g1 = gB; a.g2 = gA; a.so = 1; a.sp = (size_t)Bc;
     a.icO = icB; a.icP = icA; a.seg = (int*)(w + L.segB); a.list = (uint32_t*)(w + L.listB); a.dn = dnB;
-    hipLaunchKernelGGL(filip_invert_kernel, dim3(Bc), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(filip_invert_kernel, dim3(Bc), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(filip_gather_kernel, dim3(Bc * (TBp / 16)), dim3(256), 0, st, a);
     if (int rc = pclip_check_launch("filip backward (B side)")) return rc;
     const size_t n = (size_t)Br * Bc;

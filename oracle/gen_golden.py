@@ -23,7 +23,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+REF = next((a for a in sys.argv[1:] if not a.startswith("--")), "/root/reference")
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
@@ -187,6 +187,36 @@ def gen_filip(models, tuf):
                         lenA=_np(lA), lenB=_np(lB))
 
 
+def gen_loops(models, tu, tuf):
+    """Two epochs of the reference's own train/evaluate loops on a tiny randomly initialised
+    ESM-2 (hidden 32, 2 layers) and 8 synthetic sequence pairs: pins the loop order
+    (zero_grad / backward / step), the loss averaging and the state-dict key names."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from protein_clip_amd import synthetic as S
+    from torch.utils.data import DataLoader
+    tok = S.make_tokenizer()
+    data = S.PairDataset(8, pep_len=(5, 12), rec_len=(10, 30), seed=7)
+    out = {"peptides": data.pep, "receptors": data.rec, "batch_size": 4, "esm": {"hidden": 32, "layers": 2, "heads": 4},
+           "head": {"input_dim": 32, "embedding_dim": 16, "h1": 2, "h2": 2, "dropout": 0.0}, "lr": 1e-3, "seed": 42}
+    for name, cls, mod in (("clip", models.ExtendedCLIP, tu), ("filip", models.ExtendedFILIP, tuf)):
+        torch.manual_seed(42)
+        esm = S.make_esm(32, 2, 4)
+        for prm in esm.parameters():
+            prm.requires_grad = False
+        model = cls(32, 16, 2, 2, 0.0, esm)
+        loader = DataLoader(data, batch_size=4, shuffle=False, drop_last=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        trace = {"state_dict_keys": list(model.state_dict().keys()), "epochs": []}
+        for _ in range(2):
+            tr = mod.train(model, loader, opt, tok, "cpu")
+            ev = mod.evaluate(model, loader, tok, "cpu")
+            trace["epochs"].append({"train": float(tr), "eval": float(ev), "temperature": float(model.temperature.item())})
+        out[name] = trace
+    with open(os.path.join(OUT, "loops_trace.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.dont_write_bytecode = True
@@ -197,10 +227,13 @@ def main():
     import modules.models as models
     import modules.training_utils as tu
     import modules.training_utils_filip as tuf
-    gen_clip(tu)
-    print("clip goldens written", flush=True)
-    gen_filip(models, tuf)
-    print("filip goldens written", flush=True)
+    if "--loops-only" not in sys.argv:
+        gen_clip(tu)
+        print("clip goldens written", flush=True)
+        gen_filip(models, tuf)
+        print("filip goldens written", flush=True)
+    gen_loops(models, tu, tuf)
+    print("loop traces written", flush=True)
 
 
 if __name__ == "__main__":

@@ -79,8 +79,7 @@ class _ClipLoss(torch.autograd.Function):
         if world > 1:
             # both log-sum-exp vectors travel in one collective: [2,Bl] per rank -> [world,2,Bl]
             both = torch.stack([lse_r, lse_c])
-            gathered = torch.empty((world,) + tuple(both.shape), dtype=both.dtype, device=both.device)
-            dist.all_gather_into_tensor(gathered, both, group=group)
+            gathered = _all_gather_rows(both, group, world).view((world,) + tuple(both.shape))
             lse_r_all = gathered[:, 0].reshape(-1).contiguous()
             lse_c_all = gathered[:, 1].reshape(-1).contiguous()
             dist.all_reduce(loss, group=group)
@@ -178,7 +177,8 @@ class _FilipSim(torch.autograd.Function):
             # every rank holds a partial gradient for every B sequence: sum and hand each rank its own
             dnB = torch.empty((hB.shape[0],) + tuple(dnB_all.shape[1:]), dtype=dnB_all.dtype, device=dnB_all.device)
             dist.reduce_scatter_tensor(dnB, dnB_all, group=group)
-            dist.all_reduce(dt, group=group)
+            # dt stays this rank's share, like every shared-parameter gradient: the trainer's
+            # gradient all-reduce (SUM) completes it
         else:
             dnB = dnB_all
         dhA = K.filip_prep_bwd(hA, dnA, normalise, tsign=t)

@@ -30,9 +30,10 @@ def _world(group):
 def _gather(t, group, world):
     if world == 1:
         return t
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    # concatenated-along-dim-0 output is the layout every backend (RCCL, gloo) accepts
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous(), group=group)
-    return out
+    return out.view((world,) + tuple(t.shape))
 
 
 class ClipShardedStep:

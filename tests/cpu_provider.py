@@ -1,0 +1,146 @@
+"""A CPU stand-in for the kernel provider (the functions of ``protein_clip_amd.kernels``),
+written with plain torch ops.  TEST-ONLY: it lets the sharding / communication logic of
+``protein_clip_amd.steps`` and ``protein_clip_amd.ops`` run under ``gloo`` without a GPU.  The
+product never imports it."""
+import torch
+
+F32 = torch.float32
+
+
+def _s(t):
+    # detached: the provider returns temperature gradients explicitly, like the HIP kernels do
+    return t.detach().reshape(()).to(F32) if isinstance(t, torch.Tensor) else torch.tensor(float(t))
+
+
+def _l2(e, tval):
+    return e / e.norm(dim=-1, keepdim=True).clamp_min(1e-12) * torch.exp(tval / 2)
+
+
+def l2norm_scale_fwd(e, t):
+    return _l2(e, _s(t))
+
+
+def l2norm_scale_bwd(e, t, dx, g=None, dt=None):
+    e_ = e.detach().clone().requires_grad_(True)
+    t_ = _s(t).detach().clone().requires_grad_(True)
+    scale = 1.0 if g is None else _s(g)
+    with torch.enable_grad():   # these helpers are also called from inside autograd.Function.backward
+        (_l2(e_, t_) * dx * scale).sum().backward()
+    out_dt = t_.grad.reshape(1)
+    if dt is not None:
+        dt += out_dt
+        out_dt = dt
+    return e_.grad, out_dt
+
+
+def clip_fwd(X_own, Y_own, X_all, Y_all, row_offset=0, logits_mode=0):
+    Br, Bg = X_own.shape[0], X_all.shape[0]
+    S_rows = X_own @ Y_all.t()          # [Br,Bg]  rows of S owned
+    S_cols = Y_own @ X_all.t()          # [Br,Bg]  columns of S owned (transposed)
+    lse_r = torch.logsumexp(S_rows, 1)
+    lse_c = torch.logsumexp(S_cols, 1)
+    idx = torch.arange(Br) + row_offset
+    diag = S_rows[torch.arange(Br), idx]
+    loss = (0.5 / Bg) * (lse_r + lse_c - 2 * diag).sum().reshape(1)
+    logits = None
+    if logits_mode == 1:
+        logits = S_rows
+    elif logits_mode == 2:
+        logits = S_rows.exp()
+    return lse_r, lse_c, loss, logits
+
+
+def clip_bwd(X_own, Y_own, X_all, Y_all, lse_row_all, lse_col_all, row_offset=0, g=None):
+    Br, Bg = X_own.shape[0], X_all.shape[0]
+    scale = (0.5 / Bg) * (1.0 if g is None else _s(g))
+    own = torch.arange(Br) + row_offset
+    eye = torch.zeros(Br, Bg)
+    eye[torch.arange(Br), own] = 1.0
+    S_rows = X_own @ Y_all.t()
+    G_rows = scale * ((S_rows - lse_row_all[own][:, None]).exp() + (S_rows - lse_col_all[None, :]).exp() - 2 * eye)
+    S_cols = Y_own @ X_all.t()          # S_cols[j,i] = S[i, own j]
+    G_cols = scale * ((S_cols - lse_col_all[own][:, None]).exp() + (S_cols - lse_row_all[None, :]).exp() - 2 * eye)
+    return G_rows @ Y_all, G_cols @ X_all
+
+
+def rowce_fwd(logits, row_offset=0, Bg=None, use_dcl=False):
+    Br, Bc = logits.shape
+    Bg = Br if Bg is None else Bg
+    tgt = torch.arange(Br) + row_offset
+    l = logits.clone()
+    if use_dcl:
+        l[torch.arange(Br), tgt] = float("-inf")
+    lse = torch.logsumexp(l, 1)
+    loss = ((lse - logits[torch.arange(Br), tgt]).sum() / Bg).reshape(1)
+    return lse, loss
+
+
+def rowce_bwd(logits, lse, row_offset=0, Bg=None, use_dcl=False, g=None, gscale=1.0):
+    Br, Bc = logits.shape
+    Bg = Br if Bg is None else Bg
+    tgt = torch.arange(Br) + row_offset
+    p = (logits - lse[:, None]).exp()
+    if use_dcl:
+        p[torch.arange(Br), tgt] = 0.0
+    p[torch.arange(Br), tgt] -= 1.0
+    return p * (gscale / Bg) * (1.0 if g is None else _s(g))
+
+
+def _bf16(x):
+    return x.to(torch.bfloat16).to(F32)
+
+
+def filip_prep(h, mask, normalise, tsign=None):
+    n = h / h.norm(dim=-1, keepdim=True) if normalise else h
+    if tsign is not None and float(_s(tsign)) < 0:
+        n = -n
+    m = (mask != 0)
+    return _bf16(n) * m[..., None], m.to(torch.uint8)
+
+
+def _scores(hnA, mA, hnB, mB, t):
+    mA, mB = mA.bool(), mB.bool()
+    sim = torch.einsum("iad,jbd->ijab", hnA, hnB)
+    ok = mA[:, None, :, None] & mB[None, :, None, :]
+    sim = torch.where(ok, sim, torch.full((), torch.finfo(F32).min))
+    rA, aA = sim.max(dim=3)
+    rB, aB = sim.max(dim=2)
+    inv_t = 1.0 / _s(t).abs()
+    cA = mA.sum(1).clamp(min=1e-6).to(F32)
+    cB = mB.sum(1).clamp(min=1e-6).to(F32)
+    simA = torch.where(mA[:, None, :], rA, torch.zeros(())).sum(-1) / cA[:, None] * inv_t
+    simB = torch.where(mB[None, :, :], rB, torch.zeros(())).sum(-1) / cB[None, :] * inv_t
+    return simA, simB, aA, aB
+
+
+def filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, want_arg=True, unit_norm=False):
+    simA, simB, aA, aB = _scores(hnA, mwA, hnB, mwB, t)
+    return simA, simB, aA.to(torch.int16), aB.to(torch.int16)
+
+
+def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt=None):
+    a = hnA.detach().clone().requires_grad_(True)
+    b = hnB.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        sA, sB, _, _ = _scores(a, mwA, b, mwB, t)
+        ((sA * gA).sum() + (sB * gB).sum()).backward()
+    out_dt = (-(gA * simA + gB * simB).sum() / _s(t)).reshape(1)
+    if dt is not None:
+        dt += out_dt
+        out_dt = dt
+    return a.grad, b.grad, out_dt
+
+
+def filip_prep_bwd(h, dn, normalise, tsign=None, out=None):
+    sgn = -1.0 if (tsign is not None and float(_s(tsign)) < 0) else 1.0
+    if normalise:
+        h_ = h.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            ((h_ / h_.norm(dim=-1, keepdim=True)) * dn * sgn).sum().backward()
+        res = h_.grad
+    else:
+        res = dn * sgn
+    if out is not None:
+        out += res
+        return out
+    return res

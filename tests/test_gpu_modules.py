@@ -1,0 +1,153 @@
+"""GPU tests of the drop-in Python surface (modules.models / training_utils /
+training_utils_filip) on top of the HIP operators: the reference's own two-epoch loop traces,
+autograd through the operators, and the big-batch (GradCache-semantics) trainer."""
+import json
+import os
+
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+from oracle import pclip_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from protein_clip_amd import synthetic as S
+    from protein_clip_amd.modules import models, training_utils, training_utils_filip
+    with open(os.path.join(ROOT, "tests", "golden", "loops_trace.json")) as f:
+        trace = json.load(f)
+    return dict(S=S, models=models, tu=training_utils, tuf=training_utils_filip, trace=trace, tok=S.make_tokenizer())
+
+
+def _build(env, kind, dropout=None):
+    tr = env["trace"]
+    torch.manual_seed(tr["seed"])
+    esm = env["S"].make_esm(tr["esm"]["hidden"], tr["esm"]["layers"], tr["esm"]["heads"])
+    for prm in esm.parameters():
+        prm.requires_grad = False
+    h = tr["head"]
+    cls = env["models"].ExtendedCLIP if kind == "clip" else env["models"].ExtendedFILIP
+    return cls(h["input_dim"], h["embedding_dim"], h["h1"], h["h2"], h["dropout"] if dropout is None else dropout, esm).cuda()
+
+
+class _Pairs(torch.utils.data.Dataset):
+    def __init__(self, pep, rec):
+        self.pep, self.rec = pep, rec
+
+    def __len__(self):
+        return len(self.pep)
+
+    def __getitem__(self, i):
+        return self.pep[i], self.rec[i]
+
+
+@pytest.mark.parametrize("kind,tol", [("clip", 2e-4), ("filip", 3e-3)])
+def test_two_epoch_trace_matches_the_reference_loops(env, kind, tol):
+    """Same seed, same synthetic pairs, same Adam: per-epoch train / eval means and the learnt
+    temperature as produced by the reference's train()/evaluate() on CPU."""
+    tr = env["trace"]
+    model = _build(env, kind)
+    loader = DataLoader(_Pairs(tr["peptides"], tr["receptors"]), batch_size=tr["batch_size"], shuffle=False, drop_last=True)
+    opt = torch.optim.Adam(model.parameters(), lr=tr["lr"])
+    mod = env["tu"] if kind == "clip" else env["tuf"]
+    for want in tr[kind]["epochs"]:
+        got_tr = mod.train(model, loader, opt, env["tok"], "cuda")
+        got_ev = mod.evaluate(model, loader, env["tok"], "cuda")
+        assert abs(got_tr - want["train"]) < tol, (got_tr, want)
+        assert abs(got_ev - want["eval"]) < tol, (got_ev, want)
+        assert abs(model.temperature.item() - want["temperature"]) < tol
+
+
+def test_clip_operators_autograd(env, clip_cases):
+    from protein_clip_amd import ops
+    c = clip_cases["s2_B32_d128"]
+    e_pep = c["e_pep"].cuda().requires_grad_(True)
+    e_rec = c["e_rec"].cuda().requires_grad_(True)
+    t = c["t"].cuda().requires_grad_(True)
+    x, y = ops.l2norm_scale(e_pep, t), ops.l2norm_scale(e_rec, t)
+    loss = env["tu"]._contrastive_loss(x, y.t())
+    loss.backward()
+    torch.testing.assert_close(loss.cpu(), c["loss"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(e_pep.grad.cpu(), c["d_e_pep"], rtol=1e-4, atol=2e-7)
+    torch.testing.assert_close(e_rec.grad.cpu(), c["d_e_rec"], rtol=1e-4, atol=2e-7)
+    torch.testing.assert_close(t.grad.cpu(), c["d_t"], rtol=1e-4, atol=2e-6)
+    xs, ys = list(torch.chunk(x.detach(), 4)), list(torch.chunk(y.detach(), 4))
+    torch.testing.assert_close(env["tu"]._contrastive_loss_gc(xs, ys).cpu(), c["loss_gc4"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(env["tu"].get_logits(xs, ys).cpu(), c["exp_logits"], rtol=1e-5, atol=1e-6)
+
+
+def test_filip_score_function_and_loss_autograd(env, filip_cases):
+    FIL = env["models"].ExtendedFILIP
+    for key in ("s3_B8_TA48_TB40_d128_bf16n", "s4_B5_TA70_TB33_d128_bf16n"):
+        c = filip_cases[key]
+        a = c["hA"].cuda().requires_grad_(True)
+        b = c["hB"].cuda().requires_grad_(True)
+        t = c["t"].cuda().requires_grad_(True)
+        sA, sB = FIL._filip_similarity_score(a, b, c["maskA"].cuda(), c["maskB"].cuda(), t)
+        loss = env["tuf"]._compute_loss(sA, sB)
+        loss.backward()
+        torch.testing.assert_close(sA.detach().cpu(), c["sim_A"], rtol=2e-6, atol=2e-6)
+        torch.testing.assert_close(sB.detach().cpu(), c["sim_B"], rtol=2e-6, atol=2e-6)
+        torch.testing.assert_close(loss.detach().cpu(), c["loss"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(t.grad.cpu(), c["d_t"], rtol=1e-4, atol=1e-6)
+        for got, want in ((a.grad.cpu(), c["d_hA"]), (b.grad.cpu(), c["d_hB"])):
+            bad = ((got - want).abs() > 1e-6 + 1e-3 * want.abs()).float().mean().item()
+            assert bad <= 0.01
+            assert ((got - want).norm() / want.norm()).item() < 0.05
+        torch.testing.assert_close(env["tuf"]._contrastive_loss(c["sim_B"].cuda(), use_dcl=True).cpu(), c["loss_B_dcl"], rtol=1e-5, atol=1e-6)
+
+
+def test_filip_group_axis_variant(env, filip_cases):
+    c = filip_cases["s1_B6_TA9_TB11_d16_raw"]
+    FIL = env["models"].ExtendedFILIP
+    hA = O.bf16_round(O.filip_normalise(c["hA"])).cuda()
+    hB = O.bf16_round(O.filip_normalise(c["hB"])).cuda()
+    mA, mB = c["maskA"].cuda(), c["maskB"].cuda()
+    flat = FIL._filip_similarity_score(hA, hB, mA, mB, 1.0)
+    grouped = FIL._filip_similarity_score(hA.reshape(2, 3, 9, 16), hB.reshape(3, 2, 11, 16), mA.reshape(2, 3, 9), mB.reshape(3, 2, 11), 1.0,
+                                          include_group=True)
+    assert grouped[0].shape == (2, 3, 3, 2)
+    torch.testing.assert_close(grouped[0][1, 2], flat[0][3:6, 4:6])
+    torch.testing.assert_close(grouped[1][0, 1], flat[1][0:3, 2:4])
+
+
+def test_big_batch_trainer_equals_one_big_batch(env):
+    """train_gc with 2 sub-batches of 4 must take the same optimizer step as one plain step on
+    the 8 pairs at once (dropout off): same loss, same updated head weights."""
+    tr = env["trace"]
+    data = _Pairs(tr["peptides"], tr["receptors"])
+    m1, m2 = _build(env, "clip"), _build(env, "clip")
+    m2.load_state_dict(m1.state_dict())
+    o1 = torch.optim.SGD([p for p in m1.parameters() if p.requires_grad], lr=0.1)
+    o2 = torch.optim.SGD([p for p in m2.parameters() if p.requires_grad], lr=0.1)
+    scaler = torch.amp.GradScaler("cuda", enabled=False)
+    loss_gc = env["tu"].train_gc(m1, DataLoader(data, batch_size=4, shuffle=False), env["tok"], o1, scaler, "cuda", accumulated_batches=2)
+    loss_big = env["tu"].train(m2, DataLoader(data, batch_size=8, shuffle=False), o2, env["tok"], "cuda")
+    assert abs(loss_gc - loss_big) < 2e-5
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p1.requires_grad:
+            torch.testing.assert_close(p1, p2, rtol=2e-4, atol=2e-6, msg=lambda m: f"{n1}: {m}")
+
+
+def test_big_batch_trainer_replays_dropout(env):
+    """With dropout on, the second (graph) pass of a sub-batch must see the first pass's masks:
+    the representation recomputed in the replay equals the cached one."""
+    model = _build(env, "clip", dropout=0.5)
+    model.train()
+    tok = env["tok"]
+    batch = tok(env["trace"]["peptides"][:4], return_tensors="pt", padding=True).to("cuda")
+    batch["temperature"] = model.temperature
+    rep, snap = env["tu"]._encode_cached(model.pep_encoder, batch, "cuda")
+    keep = env["tu"]._RngSnapshot("cuda")
+    snap.restore()
+    again = model.pep_encoder(batch)
+    keep.restore()
+    torch.testing.assert_close(again.detach(), rep.detach(), rtol=0, atol=0)
+    other = model.pep_encoder(batch)   # a fresh pass draws new masks
+    assert not torch.equal(other.detach(), rep.detach())

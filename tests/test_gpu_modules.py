@@ -151,3 +151,23 @@ def test_big_batch_trainer_replays_dropout(env):
     torch.testing.assert_close(again.detach(), rep.detach(), rtol=0, atol=0)
     other = model.pep_encoder(batch)   # a fresh pass draws new masks
     assert not torch.equal(other.detach(), rep.detach())
+
+
+@pytest.mark.parametrize("script,extra", [("main", ["--accumulated-batches", "2"]), ("main_2protein_filip", ["--batch-size", "8"])])
+def test_entry_scripts_run_offline(env, script, extra, monkeypatch, tmp_path):
+    """The two entry scripts run end to end without the network (random two-layer trunk, random
+    pairs): one epoch, finite losses, the reference's CSV header and a checkpoint whose keys
+    are the reference's state-dict keys."""
+    import importlib
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr("sys.argv", [script + ".py", "--synthetic", "--epochs", "1", "--train-pairs", "32", "--eval-pairs", "16",
+                                     "--trunk-layers", "2", "--max-len", "60"] + extra)
+    mod = importlib.import_module(script)
+    train_losses, val_losses, test_loss = mod.main()
+    assert len(train_losses) == 1 and all(map(lambda v: v == v and abs(v) < 1e3, train_losses + val_losses + [test_loss]))
+    run_dir = next((tmp_path / "runs").iterdir())
+    assert (run_dir / "losses_per_epoch.txt").read_text().startswith("Epoch,Train Loss,Validation Loss\n1,")
+    keys = set(torch.load(run_dir / "best_model.pth", weights_only=True).keys())
+    kind = "clip" if script == "main" else "filip"
+    head_keys = {k for k in env["trace"][kind]["state_dict_keys"] if "esm_model" not in k}
+    assert head_keys and head_keys <= keys

@@ -184,7 +184,7 @@ def main():
         if world == 1 and os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": "filip_sim_kernel", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        roof = {"bound": "mfma", "kernel": "filip_sim_stream_kernel", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "kernel_ms": sim_ms, "algorithmic_flops_per_launch": flops}
     else:
         # CLIP alone: 16*B*d algorithmic bytes per step over the whole step time (HBM roof)

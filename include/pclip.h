@@ -138,9 +138,12 @@ int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, i
  * the kernel then keeps value and arg-max in one integer maximum per element (scores within
  * 2e-6 of the exact maximum); unit_norm = 0 makes no assumption (exact f32 maxima, slower).
  *   sim_A, sim_B [Br,Bc] f32
- *   argA [Br,Bc,TAp] u16: for each a the b attaining the max (0 where a is padding)
- *   argB [Br,Bc,TBp] u16: for each b the a attaining the max
- * (argA/argB feed the backward; pass NULL for both to skip them in inference.)
+ *   argA [Br,Bc,TAp] u16: for each valid a the b attaining the max
+ *   argB [Br,Bc,TBp] u16: for each valid b the a attaining the max
+ * (argA/argB feed the backward, which reads the entries of valid tokens only; entries of
+ * padding tokens are unspecified and may be left unwritten.  Pass NULL for both to skip them
+ * in inference.)  Setting the environment variable PCLIP_FILIP_KERNEL=old before the call
+ * selects the earlier non-streaming unit-norm kernel (kept for A/B timing).
  * TA, TB <= PCLIP_FILIP_MAX_T. */
 int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
                         const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,

@@ -8,6 +8,7 @@
 // running row maximum (elementwise, reduced across lanes once per pair) and a column
 // maximum (over registers) as soon as the tile leaves the matrix core.
 #include "pclip_common.h"
+#include <stdlib.h>
 
 #define FD 128            // padded embedding width
 #define ROWB (FD * 2)     // bytes per token row
@@ -298,9 +299,14 @@ extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, 
     PCLIP_REQUIRE((argA == nullptr) == (argB == nullptr), "filip_sim_fwd: pass both argA and argB or neither");
     if (int rc = filip_dims_ok("filip_sim_fwd", Br, TA, FD)) return rc;
     if (int rc = filip_dims_ok("filip_sim_fwd", Bc, TB, FD)) return rc;
-    if (unit_norm)
+    if (unit_norm) {
+        static const int which = [] { const char* e = getenv("PCLIP_FILIP_KERNEL"); return (e && e[0] == 'o') ? 0 : 1; }();
+        if (which)
+            return filip_sim_stream_launch(hnA, maskwA, Br, (TA + 31) / 32 * 32, hnB, maskwB, Bc, (TB + 31) / 32 * 32, t, sim_A, sim_B, argA,
+                                           argB, stream);
         return filip_sim_unit_launch(hnA, maskwA, Br, (TA + 31) / 32 * 32, hnB, maskwB, Bc, (TB + 31) / 32 * 32, t, sim_A, sim_B, argA, argB,
                                      stream);
+    }
     FilipArgs a;
     a.hnA = hnA; a.mwA = maskwA; a.Br = Br; a.TAp = (TA + 31) / 32 * 32;
     a.hnB = hnB; a.mwB = maskwB; a.Bc = Bc; a.TBp = (TB + 31) / 32 * 32;

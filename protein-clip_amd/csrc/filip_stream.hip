@@ -1,0 +1,448 @@
+// FILIP score kernel for UNIT-NORM operands, streaming form (gfx950).
+//
+// Work decomposition.  A workgroup of 16 waves (the only one on its CU) owns two A sequences;
+// their valid 32-token tiles (at most 16) are dealt one per wave (so the four SIMDs carry
+// ceil(n/4) tiles each) and stay in registers as MFMA A operands for the whole kernel.  The B
+// side is a STREAM of valid 32-token tiles — the tiles of this workgroup's chunk of B sequences
+// back to back, all-padding tiles left out — that flows through a ring of tile slots (8 KiB
+// each) in LDS, filled by LDS-DMA (global_load_lds_dwordx4, 1-KiB pieces) several tiles ahead
+// of the matrix cores.  A tile's image in LDS is [k-step 8][lane half 2][token 32] chunks of
+// 16 B — the DMA's per-lane source address does the reshaping — so a lane reads its eight MFMA
+// B fragments from ONE address register with immediate offsets, conflict-free.  One workgroup
+// barrier per epoch of SE tiles is the only synchronisation of the main loop.
+//
+// Per 32x32 tile: 8 v_mfma_f32_32x32x16_bf16 with the accumulator started at 2.0 (|a.b| <= 1,
+// so every valid similarity is a positive float in [1,3] whose bit pattern orders like its
+// value; padded pairs start at -FLT_MAX and stay negative).  The running row maximum and the
+// column maximum are then integer maxima of keys that carry the arg index in their low
+// mantissa bits (3 bits of B tile on the row side, 4 bits of accumulator register on the column
+// side); the dropped bits are replaced by their midpoint, so a score is within 2e-6 of the
+// exact maximum.  Column maxima of the A tiles held by different waves meet in LDS through a
+// 64-bit integer atomic max (key in the high word, A tile and lane half in the low word).
+// Rows finish once per (A tile, B sequence) by transposing the 32x32 keys through a per-wave
+// LDS pad; columns finish once per epoch, after its barrier, by a rotating subset of waves.
+#include "pclip_common.h"
+
+#ifndef ABL_MFMA_STEPS
+#define ABL_MFMA_STEPS 8   // timing experiments only: fewer k-steps (wrong results)
+#endif
+#define FD 128
+#define TILE_BYTES 8192
+#define SMAXJ 64              // B sequences per workgroup at most
+
+#define NEG_KEY ((int)0xFF7FFFFF)              // bits of -FLT_MAX
+#define NEG_KEY64 ((long long)0x8000000000000000LL)
+#define TWO_BITS 0x40000000
+
+#define FLAG_LAST 1u
+#define FLAG_NULL 2u
+
+struct FilipStreamArgs {
+    const uint16_t* hnA; const uint32_t* mwA; int Br, TAp;
+    const uint16_t* hnB; const uint32_t* mwB; int Bc, TBp;
+    const float* t;
+    float* simA; float* simB;
+    uint16_t* argA; uint16_t* argB;
+    int jchunk, ngroups;
+};
+
+// Geometry: 16 waves (four per SIMD, 128 registers each) with one A tile each; epochs of two
+// tiles, four epochs in the ring.
+struct StreamCfg {
+    static constexpr int NW = 16;
+    static constexpr int SE = 2;                       // tiles per epoch (one barrier each)
+    static constexpr int SNE = 4;                      // epochs held by the ring
+    static constexpr int SR = SE * SNE;                // ring slots
+    static constexpr int SMAXT = SMAXJ * 8 + SE;
+    static constexpr int S_RING = 0;
+    static constexpr int S_TR = SR * TILE_BYTES;                 // int   [NW][32][36]
+    static constexpr int S_COL = S_TR + NW * 32 * 36 * 4;        // i64   [2 par][SE][2 isel][32 c]
+    static constexpr int S_ROWP = S_COL + 2 * SE * 2 * 32 * 8;   // float [3 par][SE][16 A tiles]
+    static constexpr int S_COLP = S_ROWP + 3 * SE * 16 * 4;      // float [3 par][SE][2 isel]
+    static constexpr int S_MWA = S_COLP + 3 * SE * 2 * 4;        // u32   [2][8]
+    static constexpr int S_CNT = S_MWA + 64;                     // int   [4]: stream length
+    static constexpr int S_SCL = S_CNT + 16;                     // float [4]: 1/|t|, 1/nA[0], 1/nA[1]
+    static constexpr int S_NB = S_SCL + 16;                      // int   [SMAXJ] valid tokens of each B sequence
+    static constexpr int S_META = S_NB + SMAXJ * 4;              // uint4 [SMAXT]
+    static constexpr int S_TOTAL = S_META + SMAXT * 16;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ int and_or_i(int x, int m, int o) { return (x & m) | o; }
+__device__ __forceinline__ int max3_i(int a, int b, int c) { return max(max(a, b), c); }
+
+// sum over each 16-lane row, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+#define DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+    DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    DPP_ADD(0x141);  // row_half_mirror
+    DPP_ADD(0x140);  // row_mirror
+#undef DPP_ADD
+    return v;
+}
+// sum over each 32-lane half, result in every lane of the half
+__device__ __forceinline__ float half32_sum(float v) {
+    v = row16_sum(v);
+    return v + __shfl_xor(v, 16);
+}
+
+// One finished accumulator tile -> running row keys (elementwise) and one column key per lane.
+// The column maximum is one dependent chain of max3 (two keys at a time), which needs two
+// temporaries instead of sixteen: the kernel runs at 128 registers per lane.
+//   BPART: some columns (lanes) of the B tile are padding -> those lanes leave the row keys alone
+//          (their column result is never read).
+//   APART: some rows of the A tile are padding -> their keys are kept out of the column maximum
+//          through the lane masks rm[r] (bit l = row of register r is valid in lane l); what
+//          they add to the row keys of padding rows is never read.
+template <bool APART, bool BPART>
+__device__ __forceinline__ int tile_keys(const f32x16& acc, int (&KM)[16], int btag, bool colok, const unsigned long long (&rm)[16]) {
+    if (!BPART || colok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) KM[r] = max(KM[r], and_or_i(__float_as_int(acc[r]), ~7, btag));
+    }
+    int cb = NEG_KEY;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        int k0 = and_or_i(__float_as_int(acc[r]), ~15, r), k1 = and_or_i(__float_as_int(acc[r + 1]), ~15, r + 1);
+        if (APART) {
+            k0 = __builtin_amdgcn_inverse_ballot_w64(rm[r]) ? k0 : NEG_KEY;
+            k1 = __builtin_amdgcn_inverse_ballot_w64(rm[r + 1]) ? k1 : NEG_KEY;
+        }
+        cb = max3_i(cb, k0, k1);
+    }
+    return cb;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N < 0, "add the wait count");
+}
+
+__global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs p) {
+    using C = StreamCfg;
+    constexpr int NW = C::NW, SE = C::SE, SNE = C::SNE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    long long* col64 = reinterpret_cast<long long*>(smem + C::S_COL);
+    float* rowp = reinterpret_cast<float*>(smem + C::S_ROWP);
+    float* colpart = reinterpret_cast<float*>(smem + C::S_COLP);
+    uint32_t* mwa_l = reinterpret_cast<uint32_t*>(smem + C::S_MWA);
+    int* cnt_l = reinterpret_cast<int*>(smem + C::S_CNT);
+    float* scl_l = reinterpret_cast<float*>(smem + C::S_SCL);
+    int* nb_l = reinterpret_cast<int*>(smem + C::S_NB);
+    uint4* meta = reinterpret_cast<uint4*>(smem + C::S_META);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int grp = blockIdx.x % p.ngroups;
+    const int chunk = blockIdx.x / p.ngroups;
+    const int i0 = grp * 2;
+    const int j_begin = chunk * p.jchunk, j_end = min(p.Bc, j_begin + p.jchunk);
+    const int nj = j_end - j_begin;
+    const int ntA = p.TAp >> 5, ntB = p.TBp >> 5;
+
+    // ---- set-up: A mask words, column-key array, the B tile stream ---------------------------
+    if (tid < 16) {
+        const int isel = tid >> 3, at = tid & 7;
+        mwa_l[tid] = (i0 + isel < p.Br && at < ntA) ? p.mwA[(size_t)(i0 + isel) * ntA + at] : 0u;
+    }
+    for (int k = tid; k < 2 * SE * 2 * 32; k += NW * 64) col64[k] = NEG_KEY64;
+    if (w == 1) {  // one wave lays out the stream: lane = local B sequence
+        const int jl = lane;
+        uint32_t wd[8];
+        int nvt = 0, ntok = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            wd[k] = (jl < nj && k < ntB) ? p.mwB[(size_t)(j_begin + jl) * ntB + k] : 0u;
+            nvt += wd[k] != 0;
+            ntok += __popc(wd[k]);
+        }
+        const int mine = jl < nj ? max(nvt, 1) : 0;  // an empty sequence still gets one (empty) entry
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_up(incl, o);
+            if (lane >= o) incl += n;
+        }
+        int pos = incl - mine;
+        if (jl < nj) {
+            nb_l[jl] = ntok;
+            if (nvt == 0) {
+                meta[pos] = make_uint4(0u, 0u, (uint32_t)jl, FLAG_LAST);
+            } else {
+                int seen = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (wd[k]) {
+                        ++seen;
+                        meta[pos++] = make_uint4(wd[k], (uint32_t)((j_begin + jl) * ntB + k), (uint32_t)(jl | (k << 8)),
+                                                 seen == nvt ? FLAG_LAST : 0u);
+                    }
+            }
+        }
+        const int total = __shfl(incl, 63);
+        const int padded = (total + SE - 1) / SE * SE;
+        if (lane < padded - total) meta[total + lane] = make_uint4(0u, 0u, 0u, FLAG_NULL);
+        if (lane == 0) cnt_l[0] = padded;
+    }
+    __syncthreads();
+#define MWA(isel, at) ((uint32_t)__builtin_amdgcn_readfirstlane((int)mwa_l[(isel) * 8 + (at)]))
+
+    // ---- deal the valid A tiles of the two sequences to the waves: item k -> wave k ----------
+    int slot_isel = 0, slot_at = 0;
+    uint32_t wA = 0u;
+    {
+        int item = 0, nA0 = 0, nA1 = 0;
+        for (int isel = 0; isel < 2; ++isel)
+            for (int at = 0; at < 8; ++at) {
+                const uint32_t wd = MWA(isel, at);
+                if (isel == 0) nA0 += __popc(wd); else nA1 += __popc(wd);
+                if (wd) {
+                    if (item == w) { slot_isel = isel; slot_at = at; wA = wd; }
+                    ++item;
+                }
+            }
+        if (tid == 0) {
+            scl_l[0] = 1.f / fabsf(p.t[0]);
+            scl_l[1] = 1.f / fmaxf((float)nA0, 1e-6f);
+            scl_l[2] = 1.f / fmaxf((float)nA1, 1e-6f);
+        }
+    }
+    bf16x8 afr[8];
+    {
+        const uint16_t* src = p.hnA + ((size_t)min(i0 + slot_isel, p.Br - 1) * p.TAp + slot_at * 32 + c) * FD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) afr[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+    }
+    // retire the A-fragment loads here (an opaque use), before any LDS-DMA is in flight
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(afr[s]));
+
+    // lane masks of the A tile's valid rows, one per accumulator register (scalar registers)
+    unsigned long long rm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t lo = ((wA >> acc_row(r, 0)) & 1u) ? 0xffffffffu : 0u, hi = ((wA >> acc_row(r, 1)) & 1u) ? 0xffffffffu : 0u;
+        rm[r] = ((unsigned long long)hi << 32) | lo;
+    }
+    const bool apart = wA != 0xffffffffu;
+
+    const int T = __builtin_amdgcn_readfirstlane(cnt_l[0]);
+    const int nE = T / SE;
+
+    // LDS-DMA.  Piece s = w % 8 of a tile is its k-step s: lane l (half l / 32, token l % 32)
+    // fetches bytes [32 s + 16 half, +16) of the token's 256-byte row and lands at chunk
+    // 64 s + l of the tile image.  Wave w serves the tile q = w / 8 of every epoch.  Issued
+    // through inline asm: hipcc orders every later LDS read behind a DMA it knows of (vmcnt(0)),
+    // which would serialise the ring; this way the copies are counted by hand (one per epoch and
+    // wave, retired by the vmcnt waits in front of each epoch barrier).
+    const int piece = w & 7, dq = w >> 3;
+    const unsigned char* hnB_bytes = reinterpret_cast<const unsigned char*>(p.hnB);
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + C::S_RING) + (uint32_t)piece * 1024u;
+    auto issue_epoch = [&](int E) {
+        // the lane's source offset is recomputed here from an opaque lane id, so that it does not
+        // occupy registers (or a scratch slot) across the whole tile loop
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const uint32_t dsrc_off = (uint32_t)((ln & 31) * (FD * 2) + 32 * piece + 16 * (ln >> 5));
+        const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[E * SE + dq].y);
+        const unsigned char* src = hnB_bytes + (size_t)g * (32 * FD * 2) + dsrc_off;
+        const uint32_t dst = ring_lds + (uint32_t)((E % SNE) * SE + dq) * TILE_BYTES;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+
+    int KM[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) KM[r] = NEG_KEY;
+
+    // prologue: epochs 0 .. SNE-2 in flight, epoch 0 landed
+    for (int E = 0; E < SNE - 1; ++E)
+        if (E < nE) issue_epoch(E);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    float runB = 0.f;  // emitter threads: running column sum of the sequence being streamed
+    const bool emitter = (tid == 0 || tid == 64);
+
+    // Emits the two scores of every sequence whose last tile lies in epoch E (all of its parts
+    // are complete one barrier after that epoch's own).
+    auto emit_epoch = [&](int E) {
+        const int em_isel = tid >> 6;
+        if (emitter && i0 + em_isel < p.Br) {
+            const int par = E % 3;
+            for (int q = 0; q < SE; ++q) {
+                const uint4 m = meta[E * SE + q];
+                if (m.w & FLAG_NULL) continue;
+                runB += colpart[(par * SE + q) * 2 + em_isel];
+                if (m.w & FLAG_LAST) {
+                    const int jl = m.z & 0xff;
+                    float sa = 0.f;
+                    for (int at = 0; at < 8; ++at)
+                        if (mwa_l[em_isel * 8 + at]) sa += rowp[(par * SE + q) * 16 + em_isel * 8 + at];
+                    const size_t o = (size_t)(i0 + em_isel) * p.Bc + j_begin + jl;
+                    p.simA[o] = sa * scl_l[1 + em_isel] * scl_l[0];
+                    p.simB[o] = runB / fmaxf((float)nb_l[jl], 1e-6f) * scl_l[0];
+                    runB = 0.f;
+                }
+            }
+        }
+    };
+
+    for (int e = 0; e < nE; ++e) {
+        const bool ahead = e + SNE - 1 < nE;
+        if (ahead) issue_epoch(e + SNE - 1);
+        const int ring0 = (e % SNE) * SE;
+        const int par2 = e & 1, par3 = e % 3;
+
+        // this epoch's tile records, as scalars
+        uint32_t t_wB[SE], t_mz[SE], t_fl[SE];
+#pragma unroll
+        for (int q = 0; q < SE; ++q) {
+            const uint4 mraw = meta[e * SE + q];
+            t_wB[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mraw.x);
+            t_mz[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mraw.z);
+            t_fl[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mraw.w);
+        }
+
+#pragma unroll
+        for (int q = 0; q < SE; ++q) {
+            const uint32_t wB = t_wB[q], mz = t_mz[q], fl = t_fl[q];
+            const int bt = (mz >> 8) & 7;
+            if (wB != 0 && wA != 0) {
+                bf16x8 bfr[8];
+                {
+                    const unsigned char* base = smem + C::S_RING + (ring0 + q) * TILE_BYTES + lane * 16;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(base + 1024 * s);
+                }
+                const f32x16 two = {2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f};
+                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], two, 0, 0, 0);
+#pragma unroll
+                for (int s = 1; s < ABL_MFMA_STEPS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], bfr[s], acc, 0, 0, 0);
+#ifdef ABL_NOEPI
+                asm volatile("" ::"v"(acc));
+#else
+                const bool colok = (wB >> c) & 1u;
+                int cb;
+                if (wB == 0xffffffffu) cb = apart ? tile_keys<true, false>(acc, KM, bt, colok, rm) : tile_keys<false, false>(acc, KM, bt, colok, rm);
+                else                   cb = apart ? tile_keys<true, true>(acc, KM, bt, colok, rm) : tile_keys<false, true>(acc, KM, bt, colok, rm);
+                atomicMax(&col64[((par2 * SE + q) * 2 + slot_isel) * 32 + c], ((long long)cb << 32) | (long long)((slot_at << 1) | h));
+#endif
+            }
+            if ((fl & FLAG_LAST) && wA != 0) {
+                // ---- rows of the finished B sequence: transpose the keys, lane (row, half) scans 16 ----
+                int* tr = reinterpret_cast<int*>(smem + C::S_TR) + w * 32 * 36;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    tr[acc_row(r, h) * 36 + c] = KM[r];
+                    KM[r] = NEG_KEY;
+                }
+                __builtin_amdgcn_wave_barrier();
+                int k16[16];
+                {
+                    const int4* rp = reinterpret_cast<const int4*>(tr + c * 36 + h * 16);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int4 v = rp[q4];
+                        k16[4 * q4] = v.x; k16[4 * q4 + 1] = v.y; k16[4 * q4 + 2] = v.z; k16[4 * q4 + 3] = v.w;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int a0 = max3_i(k16[0], k16[1], k16[2]), a1 = max3_i(k16[3], k16[4], k16[5]), a2 = max3_i(k16[6], k16[7], k16[8]);
+                const int a3 = max3_i(k16[9], k16[10], k16[11]), a4 = max3_i(k16[12], k16[13], k16[14]);
+                int m = max(max3_i(a0, a1, a2), max3_i(a3, a4, k16[15]));
+                int cc = 15;
+#pragma unroll
+                for (int k = 14; k >= 0; --k) cc = (k16[k] == m) ? k : cc;
+                cc += 16 * h;
+                {
+                    const int om = __shfl_xor(m, 32), oc = __shfl_xor(cc, 32);
+                    if (om > m || (om == m && oc < cc)) { m = om; cc = oc; }
+                }
+                // every lane of both halves now holds row `c` of the tile: key m, winning lane cc
+                const bool valid = (wA >> c) & 1u;
+                const bool none = m < 0;
+                const float val = none ? -FLT_MAX : __int_as_float(and_or_i(m, ~7, 4)) - 2.0f;
+                const float rs = half32_sum(valid ? val : 0.f);
+                if (lane == 0) rowp[(par3 * SE + q) * 16 + slot_isel * 8 + slot_at] = rs;
+                if (h == 0 && p.argA)
+                    p.argA[((size_t)(i0 + slot_isel) * p.Bc + j_begin + (int)(mz & 0xff)) * p.TAp + slot_at * 32 + c] =
+                        (none || !valid) ? (uint16_t)0 : (uint16_t)((m & 7) * 32 + cc);
+            }
+        }
+
+        // epoch e+1 has landed once all but the DMAs of the later epochs are retired
+        if (ahead) wait_vmcnt<SNE - 2>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS atomics and writes are done
+        __builtin_amdgcn_s_barrier();
+
+        // ---- columns of this epoch's tiles, by SE waves (a different set every epoch) ------------
+        if (w / SE == e % (NW / SE)) {
+            const int q = w % SE, isel = h;
+            const uint4 m4 = meta[e * SE + q];
+            long long* cp = &col64[((par2 * SE + q) * 2 + isel) * 32 + c];
+            const long long key = *cp;
+            *cp = NEG_KEY64;
+            if (!(m4.w & FLAG_NULL)) {
+                const bool valid = ((m4.x >> c) & 1u) && (i0 + isel < p.Br);
+                float cv = 0.f;
+                if (valid) {
+                    const int hi = (int)(key >> 32), lo = (int)(key & 0xffffffffLL);
+                    int barg = 0;
+                    if (hi < 0) {
+                        cv = -FLT_MAX;
+                    } else {
+                        cv = __int_as_float(and_or_i(hi, ~15, 8)) - 2.0f;
+                        barg = (lo >> 1) * 32 + acc_row(hi & 15, lo & 1);
+                    }
+                    if (p.argB)
+                        p.argB[((size_t)(i0 + isel) * p.Bc + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = (uint16_t)barg;
+                }
+                const float cs = half32_sum(cv);
+                if (c == 0) colpart[(par3 * SE + q) * 2 + isel] = cs;
+            }
+        }
+        if (e > 0) emit_epoch(e - 1);
+    }
+    if (nE > 0) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        emit_epoch(nE - 1);
+    }
+}
+
+int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
+                            int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, void* stream) {
+    using C = StreamCfg;
+    FilipStreamArgs a;
+    a.hnA = hnA; a.mwA = maskwA; a.Br = Br; a.TAp = TAp;
+    a.hnB = hnB; a.mwB = maskwB; a.Bc = Bc; a.TBp = TBp;
+    a.t = t; a.simA = sim_A; a.simB = sim_B; a.argA = argA; a.argB = argB;
+    a.ngroups = (Br + 1) / 2;
+    int nchunk = (1024 + a.ngroups - 1) / a.ngroups;   // about four workgroups per CU over the launch
+    int jchunk = (Bc + nchunk - 1) / nchunk;
+    if (jchunk < 8) jchunk = Bc < 8 ? Bc : 8;
+    if (jchunk > SMAXJ) jchunk = SMAXJ;
+    nchunk = (Bc + jchunk - 1) / jchunk;
+    a.jchunk = jchunk;
+    static bool lds_set = false;
+    if (!lds_set) {
+        if (hipFuncSetAttribute((const void*)filip_sim_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C::S_TOTAL) != hipSuccess)
+            return pclip_fail(PCLIP_ELAUNCH, "filip_sim_stream_kernel: cannot raise the dynamic LDS limit");
+        lds_set = true;
+    }
+    hipLaunchKernelGGL(filip_sim_stream_kernel, dim3(a.ngroups * nchunk), dim3(C::NW * 64), C::S_TOTAL, (hipStream_t)stream, a);
+    return pclip_check_launch("filip_sim_stream_kernel");
+}

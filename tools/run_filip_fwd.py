@@ -11,6 +11,7 @@ from protein_clip_amd import kernels as K  # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 unit = (sys.argv[2] if len(sys.argv) > 2 else "unit") == "unit"
 full = len(sys.argv) > 3 and sys.argv[3] == "full"
+want_arg = not (len(sys.argv) > 4 and sys.argv[4] == "noarg")
 B, L, D = 256, 256, 128
 g = torch.Generator().manual_seed(0)
 hA = torch.randn(B, L, D, generator=g).to(torch.bfloat16).float().cuda()
@@ -30,7 +31,7 @@ torch.cuda.synchronize()
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
 for i in range(reps):
     ev[i][0].record()
-    out = K.filip_sim_fwd(hnA, mwA, L, hnB, mwB, L, t, want_arg=True, unit_norm=unit)
+    out = K.filip_sim_fwd(hnA, mwA, L, hnB, mwB, L, t, want_arg=want_arg, unit_norm=unit)
     ev[i][1].record()
 torch.cuda.synchronize()
 ms = [a.elapsed_time(b) for a, b in ev]

@@ -1,0 +1,69 @@
+// Standalone timing harness for the FILIP score kernels (no torch): random unit-norm-bounded
+// bf16 images at the benchmark shape, N timed launches with HIP events.
+//   hipcc -O3 --offload-arch=gfx950 [-DABL_...] -I../../include sim_bench.cpp ../../protein-clip_amd/csrc/filip_stream.hip ../../protein-clip_amd/csrc/filip_fast.hip -o sim_bench
+//   ./sim_bench [reps] [full|ragged] [stream|old] [arg|noarg]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+thread_local char g_pclip_err[512];
+int filip_sim_unit_launch(const uint16_t*, const uint32_t*, int, int, const uint16_t*, const uint32_t*, int, int, const float*, float*, float*,
+                          uint16_t*, uint16_t*, void*);
+int filip_sim_stream_launch(const uint16_t*, const uint32_t*, int, int, const uint16_t*, const uint32_t*, int, int, const float*, float*, float*,
+                            uint16_t*, uint16_t*, void*);
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
+
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 10;
+    const bool full = argc > 2 && !strcmp(argv[2], "full");
+    const bool old = argc > 3 && !strcmp(argv[3], "old");
+    const bool noarg = argc > 4 && !strcmp(argv[4], "noarg");
+    const int B = argc > 5 ? atoi(argv[5]) : 256;
+    const int Bc = argc > 6 ? atoi(argv[6]) : B;
+    const int L = 256, D = 128;
+    srand(1);
+    auto fill = [&](std::vector<uint16_t>& img, std::vector<uint32_t>& mw, int n, double& toks) {
+        img.assign((size_t)n * L * D, 0); mw.assign((size_t)n * 8, 0); toks = 0;
+        for (int s = 0; s < n; ++s) {
+            int len = full ? L : 128 + rand() % 129;
+            toks += len;
+            for (int t = 0; t < len; ++t) {
+                mw[s * 8 + t / 32] |= 1u << (t % 32);
+                for (int k = 0; k < D; ++k) img[((size_t)s * L + t) * D + k] = f2bf(((rand() % 2001) - 1000) * 0.00008f);
+            }
+        }
+    };
+    std::vector<uint16_t> hA, hB; std::vector<uint32_t> mA, mB; double tokA, tokB;
+    fill(hA, mA, B, tokA); fill(hB, mB, Bc, tokB);
+    uint16_t *dA, *dB, *argA, *argB; uint32_t *dmA, *dmB; float *t, *sA, *sB;
+    hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dmA, mA.size() * 4); hipMalloc(&dmB, mB.size() * 4);
+    hipMalloc(&argA, (size_t)B * Bc * L * 2); hipMalloc(&argB, (size_t)B * Bc * L * 2);
+    hipMalloc(&t, 4); hipMalloc(&sA, (size_t)B * Bc * 4); hipMalloc(&sB, (size_t)B * Bc * 4);
+    hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dmA, mA.data(), mA.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dmB, mB.data(), mB.size() * 4, hipMemcpyHostToDevice);
+    float one = 1.f; hipMemcpy(t, &one, 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    std::vector<float> ms;
+    for (int r = 0; r < reps + 3; ++r) {
+        hipEventRecord(e0, 0);
+        int rc = old ? filip_sim_unit_launch(dA, dmA, B, L, dB, dmB, Bc, L, t, sA, sB, noarg ? nullptr : argA, noarg ? nullptr : argB, 0)
+                     : filip_sim_stream_launch(dA, dmA, B, L, dB, dmB, Bc, L, t, sA, sB, noarg ? nullptr : argA, noarg ? nullptr : argB, 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        if (rc) { printf("launch failed: %s\n", g_pclip_err); return 1; }
+        float m; hipEventElapsedTime(&m, e0, e1);
+        if (r >= 3) ms.push_back(m);
+    }
+    std::sort(ms.begin(), ms.end());
+    std::vector<float> hs((size_t)B * Bc); hipMemcpy(hs.data(), sA, hs.size() * 4, hipMemcpyDeviceToHost);
+    double chk = 0; for (float v : hs) chk += v;
+    const double flops = 2.0 * D * tokA * tokB;
+    printf("%s %s %s B=%d Bc=%d: median %.3f ms  min %.3f ms  -> %.1f TFLOP/s (median)  checksum %.6f\n", old ? "old" : "stream", full ? "full" : "ragged",
+           noarg ? "noarg" : "arg", B, Bc, ms[ms.size() / 2], ms[0], flops / (ms[ms.size() / 2] * 1e-3) / 1e12, chk / hs.size());
+    return 0;
+}

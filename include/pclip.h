@@ -155,7 +155,8 @@ int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int
  * d loss / d sim_B.  Outputs (f32, OVERWRITTEN): dnA [Br,TA,128p] and dnB [Bc,TB,128p] hold
  * d loss / d (normalised operand) in the padded [.,Tp,128] layout of prep; dt is
  * ACCUMULATED: dt += -(1/t) * sum(gA*sim_A + gB*sim_B).  `ws` holds the bucketed token lists
- * (sized by pclip_filip_bwd_workspace_bytes; about 4*Br*Bc*(TAp+TBp) bytes).  The order in
+ * (sized by pclip_filip_bwd_workspace_bytes; about 4*Br*Bc*(TAp+TBp) bytes, plus eight
+ * partial copies of dnA and dnB when the operand images exceed an L2 slice).  The order in
  * which a row's contributions are summed is not fixed, so results may differ in the last
  * bits from run to run. */
 size_t pclip_filip_bwd_workspace_bytes(int Br, int TA, int Bc, int TB);

@@ -23,6 +23,14 @@
 // LDS pad; columns finish once per epoch, after its barrier, by a rotating subset of waves.
 #include "pclip_common.h"
 
+// Diagnostic build (-DSTREAM_STAMPS): every wave adds up the shader-clock cycles it spends in
+// eight segments of the main loop and stores them to g_stream_dbg[(block*16 + wave)*8 + k].
+#ifdef STREAM_STAMPS
+unsigned long long* g_stream_dbg = nullptr;
+#define STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); seg_[k] += (unsigned)(now_ - last_); last_ = now_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 #ifndef ABL_MFMA_STEPS
 #define ABL_MFMA_STEPS 8   // timing experiments only: fewer k-steps (wrong results)
 #endif
@@ -44,14 +52,22 @@ struct FilipStreamArgs {
     float* simA; float* simB;
     uint16_t* argA; uint16_t* argB;
     int jchunk, ngroups;
+#ifdef STREAM_STAMPS
+    unsigned long long* dbg;
+#endif
 };
 
-// Geometry: 16 waves (four per SIMD, 128 registers each) with one A tile each; epochs of two
-// tiles, four epochs in the ring.
+// Geometry: 16 waves (four per SIMD, 128 registers each) with one A tile each; epochs of four
+// tiles (longer epochs amortise the per-epoch barrier, DMA issue and duties: 4-5 % faster than
+// two), two epochs in the ring.
 struct StreamCfg {
     static constexpr int NW = 16;
-    static constexpr int SE = 2;                       // tiles per epoch (one barrier each)
-    static constexpr int SNE = 4;                      // epochs held by the ring
+#ifndef STREAM_SE
+#define STREAM_SE 4
+#define STREAM_SNE 2
+#endif
+    static constexpr int SE = STREAM_SE;               // tiles per epoch (one barrier each); even
+    static constexpr int SNE = STREAM_SNE;             // epochs held by the ring
     static constexpr int SR = SE * SNE;                // ring slots
     static constexpr int SMAXT = SMAXJ * 8 + SE;
     static constexpr int S_RING = 0;
@@ -91,17 +107,16 @@ __device__ __forceinline__ float half32_sum(float v) {
 // One finished accumulator tile -> running row keys (elementwise) and one column key per lane.
 // The column maximum is one dependent chain of max3 (two keys at a time), which needs two
 // temporaries instead of sixteen: the kernel runs at 128 registers per lane.
-//   BPART: some columns (lanes) of the B tile are padding -> those lanes leave the row keys alone
-//          (their column result is never read).
+//   rmask / rtag: per-lane operands of the row-key update.  A lane whose column of the B tile is
+//          valid passes (~7, B tile index); a padding column passes (0, NEG_KEY), which turns its
+//          keys into NEG_KEY and leaves the running maxima alone (its column result is never read).
 //   APART: some rows of the A tile are padding -> their keys are kept out of the column maximum
 //          through the lane masks rm[r] (bit l = row of register r is valid in lane l); what
 //          they add to the row keys of padding rows is never read.
-template <bool APART, bool BPART>
-__device__ __forceinline__ int tile_keys(const f32x16& acc, int (&KM)[16], int btag, bool colok, const unsigned long long (&rm)[16]) {
-    if (!BPART || colok) {
+template <bool APART>
+__device__ __forceinline__ int tile_keys(const f32x16& acc, int (&KM)[16], int rmask, int rtag, const unsigned long long (&rm)[16]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) KM[r] = max(KM[r], and_or_i(__float_as_int(acc[r]), ~7, btag));
-    }
+    for (int r = 0; r < 16; ++r) KM[r] = max(KM[r], and_or_i(__float_as_int(acc[r]), rmask, rtag));
     int cb = NEG_KEY;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
@@ -198,7 +213,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
 #define MWA(isel, at) ((uint32_t)__builtin_amdgcn_readfirstlane((int)mwa_l[(isel) * 8 + (at)]))
 
     // ---- deal the valid A tiles of the two sequences to the waves: item k -> wave k ----------
-    int slot_isel = 0, slot_at = 0;
+    int slot_isel = 0, slot_at = 0, n_items = 0;
     uint32_t wA = 0u;
     {
         int item = 0, nA0 = 0, nA1 = 0;
@@ -211,6 +226,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                     ++item;
                 }
             }
+        n_items = item;
         if (tid == 0) {
             scl_l[0] = 1.f / fabsf(p.t[0]);
             scl_l[1] = 1.f / fmaxf((float)nA0, 1e-6f);
@@ -241,10 +257,10 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
 
     // LDS-DMA.  Piece s = w % 8 of a tile is its k-step s: lane l (half l / 32, token l % 32)
     // fetches bytes [32 s + 16 half, +16) of the token's 256-byte row and lands at chunk
-    // 64 s + l of the tile image.  Wave w serves the tile q = w / 8 of every epoch.  Issued
-    // through inline asm: hipcc orders every later LDS read behind a DMA it knows of (vmcnt(0)),
-    // which would serialise the ring; this way the copies are counted by hand (one per epoch and
-    // wave, retired by the vmcnt waits in front of each epoch barrier).
+    // 64 s + l of the tile image.  Wave w serves the tiles w / 8, w / 8 + 2, ... of every epoch.
+    // Issued through inline asm: hipcc orders every later LDS read behind a DMA it knows of
+    // (vmcnt(0)), which would serialise the ring; this way the copies are counted by hand (SE / 2
+    // per epoch and wave, retired by the vmcnt waits in front of each epoch barrier).
     const int piece = w & 7, dq = w >> 3;
     const unsigned char* hnB_bytes = reinterpret_cast<const unsigned char*>(p.hnB);
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + C::S_RING) + (uint32_t)piece * 1024u;
@@ -254,12 +270,16 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         int ln;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
         const uint32_t dsrc_off = (uint32_t)((ln & 31) * (FD * 2) + 32 * piece + 16 * (ln >> 5));
-        const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[E * SE + dq].y);
-        const unsigned char* src = hnB_bytes + (size_t)g * (32 * FD * 2) + dsrc_off;
-        const uint32_t dst = ring_lds + (uint32_t)((E % SNE) * SE + dq) * TILE_BYTES;
-        uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+#pragma unroll
+        for (int k = 0; k < SE / 2; ++k) {   // SE * 8 pieces per epoch over 16 waves
+            const int tq = dq + 2 * k;
+            const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[E * SE + tq].y);
+            const unsigned char* src = hnB_bytes + (size_t)g * (32 * FD * 2) + dsrc_off;
+            const uint32_t dst = ring_lds + (uint32_t)((E % SNE) * SE + tq) * TILE_BYTES;
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
     };
 
     int KM[16];
@@ -299,9 +319,17 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         }
     };
 
+#ifdef STREAM_STAMPS
+    unsigned seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_readcyclecounter();
+#endif
     for (int e = 0; e < nE; ++e) {
         const bool ahead = e + SNE - 1 < nE;
         if (ahead) issue_epoch(e + SNE - 1);
+#ifdef ABL_STAGGER
+        if (w >= 8) __builtin_amdgcn_s_sleep(ABL_STAGGER);
+#endif
+        STAMP(0);
         const int ring0 = (e % SNE) * SE;
         const int par2 = e & 1, par3 = e % 3;
 
@@ -314,6 +342,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
             t_mz[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mraw.z);
             t_fl[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mraw.w);
         }
+        STAMP(1);
 
 #pragma unroll
         for (int q = 0; q < SE; ++q) {
@@ -330,15 +359,19 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], two, 0, 0, 0);
 #pragma unroll
                 for (int s = 1; s < ABL_MFMA_STEPS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], bfr[s], acc, 0, 0, 0);
+#ifdef STREAM_STAMPS
+                asm volatile("s_nop 0" ::"v"(acc));   // the matrix results have arrived
+                STAMP(2);
+#endif
 #ifdef ABL_NOEPI
                 asm volatile("" ::"v"(acc));
 #else
                 const bool colok = (wB >> c) & 1u;
-                int cb;
-                if (wB == 0xffffffffu) cb = apart ? tile_keys<true, false>(acc, KM, bt, colok, rm) : tile_keys<false, false>(acc, KM, bt, colok, rm);
-                else                   cb = apart ? tile_keys<true, true>(acc, KM, bt, colok, rm) : tile_keys<false, true>(acc, KM, bt, colok, rm);
+                const int rmask = colok ? ~7 : 0, rtag = colok ? bt : NEG_KEY;
+                const int cb = apart ? tile_keys<true>(acc, KM, rmask, rtag, rm) : tile_keys<false>(acc, KM, rmask, rtag, rm);
                 atomicMax(&col64[((par2 * SE + q) * 2 + slot_isel) * 32 + c], ((long long)cb << 32) | (long long)((slot_at << 1) | h));
 #endif
+                STAMP(3);
             }
             if ((fl & FLAG_LAST) && wA != 0) {
                 // ---- rows of the finished B sequence: transpose the keys, lane (row, half) scans 16 ----
@@ -379,18 +412,23 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 if (h == 0 && p.argA)
                     p.argA[((size_t)(i0 + slot_isel) * p.Bc + j_begin + (int)(mz & 0xff)) * p.TAp + slot_at * 32 + c] =
                         (none || !valid) ? (uint16_t)0 : (uint16_t)((m & 7) * 32 + cc);
+                STAMP(4);
             }
         }
 
         // epoch e+1 has landed once all but the DMAs of the later epochs are retired
-        if (ahead) wait_vmcnt<SNE - 2>();
+        if (ahead) wait_vmcnt<(SNE - 2) * (SE / 2)>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS atomics and writes are done
+        STAMP(5);
         __builtin_amdgcn_s_barrier();
+        STAMP(6);
 
-        // ---- columns of this epoch's tiles, by SE waves (a different set every epoch) ------------
-        if (w / SE == e % (NW / SE)) {
-            const int q = w % SE, isel = h;
+        // ---- columns of this epoch's tiles, by SE waves: waves without an A tile when there are
+        // enough of them, else a different set every epoch ----------------------------------------
+        const int duty0 = (NW - n_items >= SE) ? NW - SE : (e % (NW / SE)) * SE;
+        if (w >= duty0 && w < duty0 + SE) {
+            const int q = w - duty0, isel = h;
             const uint4 m4 = meta[e * SE + q];
             long long* cp = &col64[((par2 * SE + q) * 2 + isel) * 32 + c];
             const long long key = *cp;
@@ -415,7 +453,12 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
             }
         }
         if (e > 0) emit_epoch(e - 1);
+        STAMP(7);
     }
+#ifdef STREAM_STAMPS
+    if (lane == 0 && p.dbg)
+        for (int k = 0; k < 8; ++k) p.dbg[((size_t)blockIdx.x * NW + w) * 8 + k] = seg_[k];
+#endif
     if (nE > 0) {
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
@@ -431,6 +474,9 @@ int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br,
     a.hnB = hnB; a.mwB = maskwB; a.Bc = Bc; a.TBp = TBp;
     a.t = t; a.simA = sim_A; a.simB = sim_B; a.argA = argA; a.argB = argB;
     a.ngroups = (Br + 1) / 2;
+#ifdef STREAM_STAMPS
+    a.dbg = g_stream_dbg;
+#endif
     int nchunk = (1024 + a.ngroups - 1) / a.ngroups;   // about four workgroups per CU over the launch
     int jchunk = (Bc + nchunk - 1) / nchunk;
     if (jchunk < 8) jchunk = Bc < 8 ? Bc : 8;

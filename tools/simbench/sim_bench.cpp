@@ -16,6 +16,9 @@ int filip_sim_unit_launch(const uint16_t*, const uint32_t*, int, int, const uint
 int filip_sim_stream_launch(const uint16_t*, const uint32_t*, int, int, const uint16_t*, const uint32_t*, int, int, const float*, float*, float*,
                             uint16_t*, uint16_t*, void*);
 
+#ifdef STREAM_STAMPS
+extern unsigned long long* g_stream_dbg;
+#endif
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
 
 int main(int argc, char** argv) {
@@ -47,6 +50,10 @@ int main(int argc, char** argv) {
     hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(dmA, mA.data(), mA.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dmB, mB.data(), mB.size() * 4, hipMemcpyHostToDevice);
     float one = 1.f; hipMemcpy(t, &one, 4, hipMemcpyHostToDevice);
+#ifdef STREAM_STAMPS
+    const size_t ndbg = (size_t)8192 * 16 * 8;
+    hipMalloc(&g_stream_dbg, ndbg * 8); hipMemset(g_stream_dbg, 0, ndbg * 8);
+#endif
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<float> ms;
     for (int r = 0; r < reps + 3; ++r) {
@@ -62,6 +69,21 @@ int main(int argc, char** argv) {
     std::sort(ms.begin(), ms.end());
     std::vector<float> hs((size_t)B * Bc); hipMemcpy(hs.data(), sA, hs.size() * 4, hipMemcpyDeviceToHost);
     double chk = 0; for (float v : hs) chk += v;
+#ifdef STREAM_STAMPS
+    {   // per-segment shader-clock cycles of the last launch (stream kernel only)
+        std::vector<unsigned long long> hd(ndbg); hipMemcpy(hd.data(), g_stream_dbg, ndbg * 8, hipMemcpyDeviceToHost);
+        const char* nm[8] = {"dma-issue", "meta", "read+mfma", "keys+atomic", "row-epilogue", "vmcnt+lgkm", "barrier", "finalize+emit"};
+        double sum[8] = {0}, tot = 0; size_t nw = 0;
+        for (size_t g = 0; g < 8192; ++g) for (int w = 0; w < 16; ++w) {
+            double t = 0; for (int k = 0; k < 8; ++k) t += hd[(g * 16 + w) * 8 + k];
+            if (t == 0) continue;
+            ++nw; for (int k = 0; k < 8; ++k) sum[k] += hd[(g * 16 + w) * 8 + k];
+        }
+        for (int k = 0; k < 8; ++k) tot += sum[k];
+        for (int g : {0, 517}) for (int w = 0; w < 16; ++w) { printf("  wg %d wave %2d:", g, w); for (int k = 0; k < 8; ++k) printf(" %8llu", hd[((size_t)g * 16 + w) * 8 + k]); printf("\n"); }
+        for (int k = 0; k < 8; ++k) printf("  seg %-14s %6.1f%%  %.0f cycles/wave\n", nm[k], 100 * sum[k] / tot, sum[k] / nw);
+    }
+#endif
     const double flops = 2.0 * D * tokA * tokB;
     printf("%s %s %s B=%d Bc=%d: median %.3f ms  min %.3f ms  -> %.1f TFLOP/s (median)  checksum %.6f\n", old ? "old" : "stream", full ? "full" : "ragged",
            noarg ? "noarg" : "arg", B, Bc, ms[ms.size() / 2], ms[0], flops / (ms[ms.size() / 2] * 1e-3) / 1e12, chk / hs.size());

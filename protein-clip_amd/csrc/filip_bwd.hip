@@ -11,12 +11,17 @@
 //
 // The partner images of a whole batch (tens of MB) do not fit the 4-MiB L2 of an XCD, and
 // row gathers served from beyond L2 run at half the rate.  So the partners are cut into
-// BWD_NWIN windows; workgroup b works on window b % 8 — blocks b and b + 8 are dispatched to
-// the same XCD, so each XCD's L2 only ever sees one window's images — and writes a PARTIAL
-// gradient row; a last pass sums the partials of the eight windows.
+// windows of about 2 MB of images; a gather launch covers eight consecutive windows, with
+// workgroup b on window b % 8 — blocks b and b + 8 are dispatched to the same XCD, so each
+// XCD's L2 only ever sees one window's images during a launch — and writes (first launch) or
+// adds to (later launches, for partner sets beyond eight windows) one of eight PARTIAL
+// gradients; a last pass sums the eight partials.
 #include "pclip_common.h"
+#include <stdlib.h>
 
 #define FD 128
+#define BWD_XCDS 8          // windows per gather launch = partial gradients
+#define BWD_MAX_WINDOWS 128 // the counting sort keeps windows x 256 counters in LDS
 
 struct FilipBwdArgs {
     const uint16_t* hnP;   // partner images [Np][TPp][128] bf16
@@ -31,16 +36,24 @@ struct FilipBwdArgs {
     const float* t;
     const float* icO;      // [No] 1/max(valid own tokens, 1e-6), 0 where the sequence is empty
     const float* icP;      // [Np] same for partners
-    int* seg;              // [No][BWD_NWIN*TOp+1] bucket offsets, index = window*TOp + own token
+    int* seg;              // [No][nwt*TOp+1] bucket offsets, index = window*TOp + own token
     uint32_t* list;        // [No][Np*TPp] bucketed entries (partner << 16 | partner token)
-    float* dn;             // [nwin][No][TOp][128] f32 out: one partial gradient per partner window
-    int nwin, qpw;         // partner windows in use (1 or BWD_NWIN), partners per window
+    float* dn;             // [nslot][No][TOp][128] f32 out: partial gradients (nslot = min(nwt, 8))
+    int nwt, qpw;          // partner windows in total (1, or a multiple of 8), partners per window
+    int win0, accumulate;  // gather launch: first window it covers; add to the partials instead of overwriting
 };
 
-// inverse valid-token counts of every sequence
-__global__ __launch_bounds__(256) void filip_count_kernel(const uint32_t* __restrict__ mw, int n, int nt, float* __restrict__ ic) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n) return;
+// inverse valid-token counts of every sequence, both sides in one launch
+__global__ __launch_bounds__(256) void filip_count_kernel(const uint32_t* __restrict__ mwA, int nA, int ntA, float* __restrict__ icA,
+                                                          const uint32_t* __restrict__ mwB, int nB, int ntB, float* __restrict__ icB) {
+    int s = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t* mw = mwA;
+    float* ic = icA;
+    int nt = ntA;
+    if (s >= nA) {
+        s -= nA; mw = mwB; ic = icB; nt = ntB;
+        if (s >= nB) return;
+    }
     int c = 0;
     for (int k = 0; k < nt; ++k) c += __popc(mw[(size_t)s * nt + k]);
     ic[s] = c > 0 ? 1.f / (float)c : 0.f;
@@ -48,18 +61,20 @@ __global__ __launch_bounds__(256) void filip_count_kernel(const uint32_t* __rest
 
 // One workgroup (16 waves) per own sequence: counting sort of the valid partner tokens by
 // (partner window, own token they chose).  Eight u16 entries are read per 16-byte load.
-#define BWD_NWIN 8
-static_assert(BWD_NWIN * PCLIP_FILIP_MAX_T == 2048, "the scan below gives two buckets to each of 1024 threads");
+// Dynamic LDS: nwt * 256 counters.  (The two sides run as two launches: one launch holding
+// both measured 9 % slower than the pair — the kernel is bound by its scattered 4-byte list
+// stores, not by latency.)
 __global__ __launch_bounds__(1024) void filip_invert_kernel(FilipBwdArgs p) {
-    __shared__ int hist[BWD_NWIN * PCLIP_FILIP_MAX_T];   // [window][own token] counts, then bucket cursors
+    extern __shared__ int hist[];                        // [window][own token] counts, then bucket cursors
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int o = blockIdx.x;
     const int ntP = p.TPp >> 5;
     const int vpr = p.TPp >> 3;                          // 8-entry vectors per partner row
-    int* seg = p.seg + (size_t)o * (BWD_NWIN * p.TOp + 1);
-    hist[2 * tid] = 0;
-    hist[2 * tid + 1] = 0;
+    const int nbuck = p.nwt * PCLIP_FILIP_MAX_T;         // a multiple of 256
+    const int per = (nbuck + 1023) >> 10;                // consecutive buckets per thread in the scan
+    int* seg = p.seg + (size_t)o * (p.nwt * p.TOp + 1);
+    for (int k = tid; k < nbuck; k += 1024) hist[k] = 0;
     __syncthreads();
     const bool own_live = p.icO[o] > 0.f;
     const int nvec = own_live ? p.Np * vpr : 0;
@@ -75,9 +90,11 @@ __global__ __launch_bounds__(1024) void filip_invert_kernel(FilipBwdArgs p) {
             if ((m8 >> k) & 1u) atomicAdd(&hc[(dw[k >> 1] >> (16 * (k & 1))) & 0xffffu], 1);
     }
     __syncthreads();
-    {   // exclusive scan of the 2048 counts in (window, token) order, two per thread
-        const int v0 = hist[2 * tid], v1 = hist[2 * tid + 1];
-        const int s = v0 + v1;
+    {   // exclusive scan of the counts in (window, token) order, `per` consecutive ones per thread
+        const int b0 = tid * per;
+        int s = 0;
+        for (int k = 0; k < per; ++k)
+            if (b0 + k < nbuck) s += hist[b0 + k];
         int incl = s;
 #pragma unroll
         for (int o2 = 1; o2 < 64; o2 <<= 1) {
@@ -86,16 +103,19 @@ __global__ __launch_bounds__(1024) void filip_invert_kernel(FilipBwdArgs p) {
         }
         if (lane == 63) wsum[w] = incl;
         __syncthreads();
-        int base = 0;
-        for (int k = 0; k < w; ++k) base += wsum[k];
-        const int e0 = base + incl - s, e1 = e0 + v0;
-        hist[2 * tid] = e0;
-        hist[2 * tid + 1] = e1;
-        // counts of tokens >= TOp are zero, so their offsets equal the next stored one
-        const int x = (2 * tid) / PCLIP_FILIP_MAX_T, a0 = (2 * tid) % PCLIP_FILIP_MAX_T;
-        if (a0 < p.TOp) seg[x * p.TOp + a0] = e0;
-        if (a0 + 1 < p.TOp) seg[x * p.TOp + a0 + 1] = e1;
-        if (tid == 1023) seg[BWD_NWIN * p.TOp] = base + incl;
+        int run = incl - s;
+        for (int k = 0; k < w; ++k) run += wsum[k];
+        for (int k = 0; k < per; ++k) {
+            const int b = b0 + k;
+            if (b >= nbuck) break;
+            const int n = hist[b];
+            hist[b] = run;
+            // counts of tokens >= TOp are zero, so their offsets equal the next stored one
+            const int x = b / PCLIP_FILIP_MAX_T, a = b - x * PCLIP_FILIP_MAX_T;
+            if (a < p.TOp) seg[x * p.TOp + a] = run;
+            run += n;
+        }
+        if (tid == 1023) seg[p.nwt * p.TOp] = run;
     }
     __syncthreads();
     uint32_t* list = p.list + (size_t)o * p.Np * p.TPp;
@@ -122,12 +142,20 @@ __global__ __launch_bounds__(1024) void filip_invert_kernel(FilipBwdArgs p) {
 __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
     const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
     const int chunks = p.TOp >> 4;
-    const int x = blockIdx.x % p.nwin, blk = blockIdx.x / p.nwin;
+    const int nslot = p.nwt < BWD_XCDS ? p.nwt : BWD_XCDS;
+    const int slot = blockIdx.x % nslot, blk = blockIdx.x / nslot;
+    const int x = p.win0 + slot;
     const int o = blk / chunks;
     const int a = (blk - o * chunks) * 16 + grp;
     const int q_lo = x * p.qpw, q_hi = min(p.Np, q_lo + p.qpw);
     const bool valid = (p.mwO[(size_t)o * (p.TOp >> 5) + (a >> 5)] >> (a & 31)) & 1u;
+    float4* out = reinterpret_cast<float4*>(p.dn + (((size_t)slot * p.No + o) * p.TOp + a) * FD + l16 * 8);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.accumulate) {
+        const float4 u = out[0], v = out[1];
+        acc[0] = u.x; acc[1] = u.y; acc[2] = u.z; acc[3] = u.w;
+        acc[4] = v.x; acc[5] = v.y; acc[6] = v.z; acc[7] = v.w;
+    }
     if (valid && q_lo < q_hi) {
         const float inv_t = 1.f / fabsf(p.t[0]);
         const float c1 = p.icO[o] * inv_t;
@@ -156,7 +184,7 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
                 for (int e = 0; e < 8; ++e) acc[e] += ws[k] * (float)rows[k][e];
         }
         // partner-side max terms of this window that chose this token: its bucket of the sorted list
-        const int* seg = p.seg + (size_t)o * (BWD_NWIN * p.TOp + 1) + x * p.TOp + a;
+        const int* seg = p.seg + (size_t)o * (p.nwt * p.TOp + 1) + x * p.TOp + a;
         const uint32_t* list = p.list + (size_t)o * p.Np * p.TPp;
         const int end = seg[1];
         for (int pos0 = seg[0]; pos0 < end; pos0 += 16) {
@@ -182,17 +210,16 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
                 for (int e = 0; e < 8; ++e) acc[e] += ws[k] * (float)rows[k][e];
         }
     }
-    float4* out = reinterpret_cast<float4*>(p.dn + (((size_t)x * p.No + o) * p.TOp + a) * FD + l16 * 8);
     out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
-// out = sum of the nwin partial gradients (n4 float4 each)
-__global__ __launch_bounds__(256) void filip_window_sum_kernel(const float4* __restrict__ part, size_t n4, int nwin, float4* __restrict__ out) {
+// out = sum of the nslot partial gradients (n4 float4 each)
+__global__ __launch_bounds__(256) void filip_window_sum_kernel(const float4* __restrict__ part, size_t n4, int nslot, float4* __restrict__ out) {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n4) return;
     float4 s = part[k];
-    for (int x = 1; x < nwin; ++x) {
+    for (int x = 1; x < nslot; ++x) {
         const float4 v = part[(size_t)x * n4 + k];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -216,26 +243,49 @@ __global__ __launch_bounds__(256) void filip_dt_kernel(const float* __restrict__
 // ---- host side -------------------------------------------------------------------------
 static inline int tp32(int T) { return (T + 31) / 32 * 32; }
 
+// Window plan of one gather side.  One window when the partner images fit the budget (2 MB by
+// default: half an XCD's L2; PCLIP_FILIP_BWD_WINDOW_KB overrides it, for tests), else windows of
+// about that size in multiples of eight.
+struct BwdPlan { int nwt, qpw; };
+static size_t bwd_window_bytes() {
+    const char* e = getenv("PCLIP_FILIP_BWD_WINDOW_KB");   // read on every call: a test may change it
+    const long kb = e ? atol(e) : 0;
+    return kb > 0 ? (size_t)kb << 10 : (size_t)2 << 20;
+}
+static BwdPlan bwd_plan(int Np, int TPp) {
+    const size_t per = (size_t)TPp * FD * 2, budget = bwd_window_bytes();
+    BwdPlan pl;
+    if ((size_t)Np * per <= budget || Np < BWD_XCDS) { pl.nwt = 1; pl.qpw = Np; return pl; }
+    int qpw = (int)(budget / per);
+    if (qpw < 1) qpw = 1;
+    int nwt = (Np + qpw - 1) / qpw;
+    nwt = (nwt + BWD_XCDS - 1) / BWD_XCDS * BWD_XCDS;
+    if (nwt > BWD_MAX_WINDOWS) {
+        nwt = BWD_MAX_WINDOWS;
+        qpw = (Np + nwt - 1) / nwt;
+    }
+    pl.nwt = nwt; pl.qpw = qpw;
+    return pl;
+}
+
 struct BwdWs {
     size_t listA, listB, segA, segB, icA, icB, partA, partB, total;
-    int nwinA, nwinB;   // partner windows of the A-side pass (partners = B) and of the B-side pass
+    BwdPlan planA, planB;   // A-side pass (partners = B) and B-side pass (partners = A)
 };
-// One window when the partner images fit an XCD's L2 with room to spare, else BWD_NWIN.
-static int bwd_windows(int Np, int TPp) { return (size_t)Np * TPp * FD * 2 > ((size_t)3 << 19) && Np >= BWD_NWIN ? BWD_NWIN : 1; }
 static BwdWs bwd_ws_layout(int Br, int TA, int Bc, int TB) {
     const size_t TAp = tp32(TA), TBp = tp32(TB);
     BwdWs w;
+    w.planA = bwd_plan(Bc, (int)TBp);
+    w.planB = bwd_plan(Br, (int)TAp);
     size_t off = 0;
     w.listA = off; off += pclip_align_up((size_t)Br * Bc * TBp * 4, 256);   // buckets of B tokens per A sequence
     w.listB = off; off += pclip_align_up((size_t)Bc * Br * TAp * 4, 256);   // buckets of A tokens per B sequence
-    w.segA = off;  off += pclip_align_up((size_t)Br * (BWD_NWIN * TAp + 1) * 4, 256);
-    w.segB = off;  off += pclip_align_up((size_t)Bc * (BWD_NWIN * TBp + 1) * 4, 256);
+    w.segA = off;  off += pclip_align_up((size_t)Br * (w.planA.nwt * TAp + 1) * 4, 256);
+    w.segB = off;  off += pclip_align_up((size_t)Bc * (w.planB.nwt * TBp + 1) * 4, 256);
     w.icA = off;   off += pclip_align_up((size_t)Br * 4, 256);
     w.icB = off;   off += pclip_align_up((size_t)Bc * 4, 256);
-    w.nwinA = bwd_windows(Bc, (int)TBp);
-    w.nwinB = bwd_windows(Br, (int)TAp);
-    w.partA = off; off += w.nwinA > 1 ? pclip_align_up((size_t)w.nwinA * Br * TAp * FD * 4, 256) : 0;   // window partials of dnA
-    w.partB = off; off += w.nwinB > 1 ? pclip_align_up((size_t)w.nwinB * Bc * TBp * FD * 4, 256) : 0;
+    w.partA = off; off += w.planA.nwt > 1 ? pclip_align_up((size_t)BWD_XCDS * Br * TAp * FD * 4, 256) : 0;   // partials of dnA
+    w.partB = off; off += w.planB.nwt > 1 ? pclip_align_up((size_t)BWD_XCDS * Bc * TBp * FD * 4, 256) : 0;
     w.total = off;
     return w;
 }
@@ -243,6 +293,21 @@ static BwdWs bwd_ws_layout(int Br, int TA, int Bc, int TB) {
 extern "C" size_t pclip_filip_bwd_workspace_bytes(int Br, int TA, int Bc, int TB) {
     if (Br < 1 || Bc < 1 || TA < 1 || TB < 1) return 0;
     return bwd_ws_layout(Br, TA, Bc, TB).total;
+}
+
+// gather launches of one side (eight windows each) and the sum of the partials
+static void bwd_gather_side(FilipBwdArgs a, float* part, float* dn, hipStream_t st) {
+    const int nslot = a.nwt < BWD_XCDS ? a.nwt : BWD_XCDS;
+    a.dn = a.nwt > 1 ? part : dn;
+    for (int w0 = 0; w0 < a.nwt; w0 += BWD_XCDS) {
+        a.win0 = w0;
+        a.accumulate = w0 > 0;
+        hipLaunchKernelGGL(filip_gather_kernel, dim3(a.No * (a.TOp / 16) * nslot), dim3(256), 0, st, a);
+    }
+    if (a.nwt > 1) {
+        const size_t n4 = (size_t)a.No * a.TOp * FD / 4;
+        hipLaunchKernelGGL(filip_window_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float4*)part, n4, nslot, (float4*)dn);
+    }
 }
 
 extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
@@ -261,34 +326,33 @@ extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, 
     char* w = (char*)ws;
     float* icA = (float*)(w + L.icA);
     float* icB = (float*)(w + L.icB);
-    hipLaunchKernelGGL(filip_count_kernel, dim3((Br + 255) / 256), dim3(256), 0, st, maskwA, Br, TAp / 32, icA);
-    hipLaunchKernelGGL(filip_count_kernel, dim3((Bc + 255) / 256), dim3(256), 0, st, maskwB, Bc, TBp / 32, icB);
-    FilipBwdArgs a;
+    hipLaunchKernelGGL(filip_count_kernel, dim3((Br + Bc + 255) / 256), dim3(256), 0, st, maskwA, Br, TAp / 32, icA, maskwB, Bc, TBp / 32, icB);
+    FilipBwdArgs a, b;
     // gradient of the A images: own = A(i), partner = B(j), pair = i*Bc + j
     a.hnP = hnB; a.mwO = maskwA; a.mwP = maskwB; a.No = Br; a.TOp = TAp; a.Np = Bc; a.TPp = TBp;
     a.arg1 = argA; a.arg2 = argB; a.g1 = gA; a.g2 = gB; a.so = (size_t)Bc; a.sp = 1; a.t = t;
-    a.icO = icA; a.icP = icB; a.seg = (int*)(w + L.segA); a.list = (uint32_t*)(w + L.listA);
-    a.nwin = L.nwinA; a.qpw = a.nwin > 1 ? (Bc + BWD_NWIN - 1) / BWD_NWIN : Bc;
-    a.dn = a.nwin > 1 ? (float*)(w + L.partA) : dnA;
-    hipLaunchKernelGGL(filip_invert_kernel, dim3(Br), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(filip_gather_kernel, dim3(Br * (TAp / 16) * a.nwin), dim3(256), 0, st, a);
-    if (a.nwin > 1) {
-        const size_t n4 = (size_t)Br * TAp * FD / 4;
-        hipLaunchKernelGGL(filip_window_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float4*)a.dn, n4, a.nwin, (float4*)dnA);
-    }
-    if (int rc = pclip_check_launch("filip backward (A side)")) return rc;
+    a.icO = icA; a.icP = icB; a.seg = (int*)(w + L.segA); a.list = (uint32_t*)(w + L.listA); a.dn = nullptr;
+    a.nwt = L.planA.nwt; a.qpw = L.planA.qpw; a.win0 = 0; a.accumulate = 0;
     // gradient of the B images: own = B(j), partner = A(i), pair = i*Bc + j
-    a.hnP = hnA; a.mwO = maskwB; a.mwP = maskwA; a.No = Bc; a.TOp = TBp; a.Np = Br; a.TPp = TAp;
-    a.arg1 = argB; a.arg2 = argA; a.g1 = gB; a.g2 = gA; a.so = 1; a.sp = (size_t)Bc;
-    a.icO = icB; a.icP = icA; a.seg = (int*)(w + L.segB); a.list = (uint32_t*)(w + L.listB);
-    a.nwin = L.nwinB; a.qpw = a.nwin > 1 ? (Br + BWD_NWIN - 1) / BWD_NWIN : Br;
-    a.dn = a.nwin > 1 ? (float*)(w + L.partB) : dnB;
-    hipLaunchKernelGGL(filip_invert_kernel, dim3(Bc), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(filip_gather_kernel, dim3(Bc * (TBp / 16) * a.nwin), dim3(256), 0, st, a);
-    if (a.nwin > 1) {
-        const size_t n4 = (size_t)Bc * TBp * FD / 4;
-        hipLaunchKernelGGL(filip_window_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float4*)a.dn, n4, a.nwin, (float4*)dnB);
+    b.hnP = hnA; b.mwO = maskwB; b.mwP = maskwA; b.No = Bc; b.TOp = TBp; b.Np = Br; b.TPp = TAp;
+    b.arg1 = argB; b.arg2 = argA; b.g1 = gB; b.g2 = gA; b.so = 1; b.sp = (size_t)Bc; b.t = t;
+    b.icO = icB; b.icP = icA; b.seg = (int*)(w + L.segB); b.list = (uint32_t*)(w + L.listB); b.dn = nullptr;
+    b.nwt = L.planB.nwt; b.qpw = L.planB.qpw; b.win0 = 0; b.accumulate = 0;
+    const int nwt_max = a.nwt > b.nwt ? a.nwt : b.nwt;
+    const size_t hist_bytes = (size_t)nwt_max * PCLIP_FILIP_MAX_T * 4;
+    if (hist_bytes > 48 * 1024) {
+        static size_t raised = 0;
+        if (hist_bytes > raised) {
+            if (hipFuncSetAttribute((const void*)filip_invert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes) != hipSuccess)
+                return pclip_fail(PCLIP_ELAUNCH, "filip_invert_kernel: cannot raise the dynamic LDS limit");
+            raised = hist_bytes;
+        }
     }
+    hipLaunchKernelGGL(filip_invert_kernel, dim3(Br), dim3(1024), (size_t)a.nwt * PCLIP_FILIP_MAX_T * 4, st, a);
+    bwd_gather_side(a, (float*)(w + L.partA), dnA, st);
+    if (int rc = pclip_check_launch("filip backward (A side)")) return rc;
+    hipLaunchKernelGGL(filip_invert_kernel, dim3(Bc), dim3(1024), (size_t)b.nwt * PCLIP_FILIP_MAX_T * 4, st, b);
+    bwd_gather_side(b, (float*)(w + L.partB), dnB, st);
     if (int rc = pclip_check_launch("filip backward (B side)")) return rc;
     const size_t n = (size_t)Br * Bc;
     const int blocks = (int)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);

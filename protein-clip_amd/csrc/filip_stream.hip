@@ -356,9 +356,15 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                     for (int s = 0; s < 8; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(base + 1024 * s);
                 }
                 const f32x16 two = {2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f};
+#ifdef ABL_PRIO
+                __builtin_amdgcn_s_setprio(ABL_PRIO);
+#endif
                 f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], two, 0, 0, 0);
 #pragma unroll
                 for (int s = 1; s < ABL_MFMA_STEPS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], bfr[s], acc, 0, 0, 0);
+#ifdef ABL_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef STREAM_STAMPS
                 asm volatile("s_nop 0" ::"v"(acc));   // the matrix results have arrived
                 STAMP(2);

@@ -266,6 +266,38 @@ def test_filip_backward_matches_oracle(K, filip_cases):
         close(dt, dt_ref.reshape(1), 1e-4, 1e-5)
 
 
+def test_filip_backward_partner_windows_equal_single_window(K, monkeypatch):
+    """The backward cuts the partner sequences into L2-sized windows (eight per gather launch,
+    later launches accumulating).  Forced here with a tiny window budget on a ragged batch whose
+    size is no multiple of eight and which holds an empty sequence; the result must equal the
+    single-window path up to summation order."""
+    gen = torch.Generator().manual_seed(5)
+    B, TA, TB, d = 19, 40, 61, 128
+    hA, hB = torch.randn(B, TA, d, generator=gen), torch.randn(B, TB, d, generator=gen)
+    lA, lB = torch.randint(1, TA + 1, (B,), generator=gen), torch.randint(1, TB + 1, (B,), generator=gen)
+    lB[3] = 0
+    mA = (torch.arange(TA)[None] < lA[:, None]).to(torch.uint8)
+    mB = (torch.arange(TB)[None] < lB[:, None]).to(torch.uint8)
+    t = torch.tensor(1.0)
+    gA, gB = torch.randn(B, B, generator=gen), torch.randn(B, B, generator=gen)
+    hnA, mwA, hnB, mwB, simA, simB, argA, argB = _filip_fwd(K, hA, hB, mA, mB, t, normalise=True)
+    outs = []
+    for kb in (None, "16", "40"):
+        if kb is None:
+            monkeypatch.delenv("PCLIP_FILIP_BWD_WINDOW_KB", raising=False)
+        else:
+            monkeypatch.setenv("PCLIP_FILIP_BWD_WINDOW_KB", kb)
+        outs.append(K.filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, dev(t.reshape(1)), simA, simB, argA, argB, dev(gA), dev(gB)))
+    monkeypatch.delenv("PCLIP_FILIP_BWD_WINDOW_KB", raising=False)
+    for dnA, dnB, dt in outs[1:]:
+        close(dnA, outs[0][0].cpu(), 1e-5, 1e-6)
+        close(dnB, outs[0][1].cpu(), 1e-5, 1e-6)
+        # scores against the empty sequence are -inf (a sum of -FLT_MAX), which makes dt NaN in
+        # the reference as well: only require that both paths agree
+        torch.testing.assert_close(dt.cpu(), outs[0][2].cpu(), rtol=1e-6, atol=1e-6, equal_nan=True)
+    assert outs[0][0].abs().sum() > 0 and torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+
+
 def test_filip_negative_temperature(K, filip_cases):
     c = filip_cases["s1_B6_TA9_TB11_d16_raw"]
     t = torch.tensor(-0.9)

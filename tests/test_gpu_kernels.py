@@ -352,3 +352,36 @@ def test_filip_benchmark_size_matches_reference_scores(K):
     # and the scores of a sub-batch are the corresponding block of the full result
     sub = _filip_fwd(K, hA[:16], hB[32:48], mA[:16], mB[32:48], torch.tensor(1.0), normalise=True)
     assert torch.allclose(sub[4], simA[:16, 32:48], atol=1e-6) and torch.allclose(sub[5], simB[:16, 32:48], atol=1e-6)
+
+
+def test_filip_rank_shape_decomposes_over_partner_blocks(K):
+    """One rank of a 3-GPU job: 64 A sequences against 3 x 256 gathered B sequences, L = 256
+    (the backward then needs three gather launches of eight 2-MB windows each).  The two
+    directions are independent per sequence pair (models.py:332-351), so the scores of a column
+    block equal the scores computed against that block alone, and the A gradient is the sum of
+    the per-block A gradients."""
+    gen = torch.Generator().manual_seed(11)
+    Br, Bc, L, d, blk = 64, 768, 256, 128, 256
+    hA = O.bf16_round(torch.randn(Br, L, d, generator=gen))
+    hB = O.bf16_round(torch.randn(Bc, L, d, generator=gen))
+    mA = O.right_padded_masks(torch.randint(100, L + 1, (Br,), generator=gen), L)
+    mB = O.right_padded_masks(torch.randint(100, L + 1, (Bc,), generator=gen), L)
+    t = dev(torch.tensor([1.0]))
+    gA, gB = dev(torch.randn(Br, Bc, generator=gen) / Bc), dev(torch.randn(Br, Bc, generator=gen) / Bc)
+    hnA, mwA = K.filip_prep(dev(hA), dev(mA), True, tsign=t)
+    hnB, mwB = K.filip_prep(dev(hB), dev(mB), True)
+    simA, simB, argA, argB = K.filip_sim_fwd(hnA, mwA, L, hnB, mwB, L, t, unit_norm=True)
+    dnA, dnB, dt = K.filip_sim_bwd(hnA, mwA, L, hnB, mwB, L, t, simA, simB, argA, argB, gA, gB)
+    dnA_sum = torch.zeros_like(dnA)
+    dt_sum = torch.zeros_like(dt)
+    for k in range(Bc // blk):
+        sl = slice(k * blk, (k + 1) * blk)
+        sa, sb, aa, ab = K.filip_sim_fwd(hnA, mwA, L, hnB[sl].contiguous(), mwB[sl].contiguous(), L, t, unit_norm=True)
+        assert torch.equal(sa, simA[:, sl]) and torch.equal(sb, simB[:, sl])
+        da, db, dtk = K.filip_sim_bwd(hnA, mwA, L, hnB[sl].contiguous(), mwB[sl].contiguous(), L, t, sa, sb, aa, ab,
+                                      gA[:, sl].contiguous(), gB[:, sl].contiguous())
+        dnA_sum += da
+        dt_sum += dtk
+        close(dnB[sl], db.cpu(), 1e-5, 1e-7)
+    close(dnA, dnA_sum.cpu(), 1e-4, 1e-7)
+    close(dt, dt_sum.cpu(), 1e-4, 1e-6)

@@ -160,15 +160,67 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     const int c = lane & 31, h = lane >> 5;
     const int grp = blockIdx.x % p.ngroups;
     const int chunk = blockIdx.x / p.ngroups;
-    const int i0 = grp * 2;
     const int j_begin = chunk * p.jchunk, j_end = min(p.Bc, j_begin + p.jchunk);
     const int nj = j_end - j_begin;
     const int ntA = p.TAp >> 5, ntB = p.TBp >> 5;
 
+    // ---- which two A sequences: pairs whose valid-tile counts sum to a multiple of four --------
+    // Sixteen waves sit on four SIMDs, so a workgroup takes ceil(tiles / 4) tile rounds per B
+    // tile: 13 tiles cost as much as 16.  Every workgroup derives the same pairing from the mask
+    // words alone (ranks by index order inside the classes tiles mod 4; class 0 pairs with
+    // itself, 2 with itself, 1 with 3; what is left over pairs up in index order).  Batches
+    // beyond one sequence per thread keep the neighbours (2g, 2g + 1).
+    int iseq[2] = {grp * 2, grp * 2 + 1 < p.Br ? grp * 2 + 1 : -1};
+#ifndef ABL_NOPAIR
+    if (p.Br <= NW * 64) {
+        int* wtot = reinterpret_cast<int*>(smem + C::S_RING);                   // [NW][4] class counts per wave
+        uint16_t* pairmem = reinterpret_cast<uint16_t*>(smem + C::S_RING + 1024);  // [ngroups][2]
+        int cls = -1;
+        if (tid < p.Br) {
+            int nt = 0;
+            for (int k = 0; k < ntA; ++k) nt += p.mwA[(size_t)tid * ntA + k] != 0u;
+            cls = nt & 3;
+        }
+        int rank = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned long long m = __ballot(cls == r);
+            if (cls == r) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wtot[w * 4 + r] = __popcll(m);
+        }
+        for (int k = tid; k < 2 * p.ngroups; k += NW * 64) pairmem[k] = 0xFFFFu;
+        __syncthreads();
+        int n[4] = {0, 0, 0, 0};
+        for (int k = 0; k < NW; ++k) {
+            const int4 v = *reinterpret_cast<const int4*>(wtot + k * 4);
+            if (k < w && cls >= 0) rank += cls == 0 ? v.x : cls == 1 ? v.y : cls == 2 ? v.z : v.w;
+            n[0] += v.x; n[1] += v.y; n[2] += v.z; n[3] += v.w;
+        }
+        if (cls >= 0) {
+            const int p0 = n[0] >> 1, p2 = n[2] >> 1, m13 = min(n[1], n[3]);
+            int pid, pos, pool = -1;
+            if (cls == 0)      { if (rank < 2 * p0) { pid = rank >> 1; pos = rank & 1; } else pool = 0; }
+            else if (cls == 2) { if (rank < 2 * p2) { pid = p0 + (rank >> 1); pos = rank & 1; } else pool = n[0] & 1; }
+            else               { if (rank < m13) { pid = p0 + p2 + rank; pos = cls == 3; } else pool = (n[0] & 1) + (n[2] & 1) + rank - m13; }
+            if (pool >= 0) { pid = p0 + p2 + m13 + (pool >> 1); pos = pool & 1; }
+            pairmem[2 * pid + pos] = (uint16_t)tid;
+        }
+        __syncthreads();
+        const int a0 = pairmem[2 * grp], a1 = pairmem[2 * grp + 1];
+        iseq[0] = a0 == 0xFFFF ? -1 : a0;
+        iseq[1] = a1 == 0xFFFF ? -1 : a1;
+        if (iseq[0] < 0) { iseq[0] = iseq[1]; iseq[1] = -1; }
+        __syncthreads();   // the ring region is handed to the LDS-DMA below
+    }
+#endif
+    iseq[0] = __builtin_amdgcn_readfirstlane(iseq[0]);
+    iseq[1] = __builtin_amdgcn_readfirstlane(iseq[1]);
+#define ISEQ(isel) ((isel) ? iseq[1] : iseq[0])
+
     // ---- set-up: A mask words, column-key array, the B tile stream ---------------------------
     if (tid < 16) {
         const int isel = tid >> 3, at = tid & 7;
-        mwa_l[tid] = (i0 + isel < p.Br && at < ntA) ? p.mwA[(size_t)(i0 + isel) * ntA + at] : 0u;
+        mwa_l[tid] = (ISEQ(isel) >= 0 && at < ntA) ? p.mwA[(size_t)ISEQ(isel) * ntA + at] : 0u;
     }
     for (int k = tid; k < 2 * SE * 2 * 32; k += NW * 64) col64[k] = NEG_KEY64;
     if (w == 1) {  // one wave lays out the stream: lane = local B sequence
@@ -235,7 +287,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     }
     bf16x8 afr[8];
     {
-        const uint16_t* src = p.hnA + ((size_t)min(i0 + slot_isel, p.Br - 1) * p.TAp + slot_at * 32 + c) * FD + 8 * h;
+        const uint16_t* src = p.hnA + ((size_t)max(ISEQ(slot_isel), 0) * p.TAp + slot_at * 32 + c) * FD + 8 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) afr[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
     }
@@ -299,7 +351,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     // are complete one barrier after that epoch's own).
     auto emit_epoch = [&](int E) {
         const int em_isel = tid >> 6;
-        if (emitter && i0 + em_isel < p.Br) {
+        if (emitter && ISEQ(em_isel) >= 0) {
             const int par = E % 3;
             for (int q = 0; q < SE; ++q) {
                 const uint4 m = meta[E * SE + q];
@@ -310,7 +362,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                     float sa = 0.f;
                     for (int at = 0; at < 8; ++at)
                         if (mwa_l[em_isel * 8 + at]) sa += rowp[(par * SE + q) * 16 + em_isel * 8 + at];
-                    const size_t o = (size_t)(i0 + em_isel) * p.Bc + j_begin + jl;
+                    const size_t o = (size_t)ISEQ(em_isel) * p.Bc + j_begin + jl;
                     p.simA[o] = sa * scl_l[1 + em_isel] * scl_l[0];
                     p.simB[o] = runB / fmaxf((float)nb_l[jl], 1e-6f) * scl_l[0];
                     runB = 0.f;
@@ -362,6 +414,17 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], two, 0, 0, 0);
 #pragma unroll
                 for (int s = 1; s < ABL_MFMA_STEPS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], bfr[s], acc, 0, 0, 0);
+#ifndef ABL_NOHOIST
+                // four fragment reads in flight ahead of the matrix instructions (16 registers):
+                // one LDS latency per tile instead of four, 2 % faster
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
 #ifdef ABL_PRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -416,7 +479,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 const float rs = half32_sum(valid ? val : 0.f);
                 if (lane == 0) rowp[(par3 * SE + q) * 16 + slot_isel * 8 + slot_at] = rs;
                 if (h == 0 && p.argA)
-                    p.argA[((size_t)(i0 + slot_isel) * p.Bc + j_begin + (int)(mz & 0xff)) * p.TAp + slot_at * 32 + c] =
+                    p.argA[((size_t)ISEQ(slot_isel) * p.Bc + j_begin + (int)(mz & 0xff)) * p.TAp + slot_at * 32 + c] =
                         (none || !valid) ? (uint16_t)0 : (uint16_t)((m & 7) * 32 + cc);
                 STAMP(4);
             }
@@ -440,7 +503,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
             const long long key = *cp;
             *cp = NEG_KEY64;
             if (!(m4.w & FLAG_NULL)) {
-                const bool valid = ((m4.x >> c) & 1u) && (i0 + isel < p.Br);
+                const bool valid = ((m4.x >> c) & 1u) && (ISEQ(isel) >= 0);
                 float cv = 0.f;
                 if (valid) {
                     const int hi = (int)(key >> 32), lo = (int)(key & 0xffffffffLL);
@@ -452,7 +515,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                         barg = (lo >> 1) * 32 + acc_row(hi & 15, lo & 1);
                     }
                     if (p.argB)
-                        p.argB[((size_t)(i0 + isel) * p.Bc + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = (uint16_t)barg;
+                        p.argB[((size_t)ISEQ(isel) * p.Bc + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = (uint16_t)barg;
                 }
                 const float cs = half32_sum(cv);
                 if (c == 0) colpart[(par3 * SE + q) * 2 + isel] = cs;

@@ -30,10 +30,12 @@ int main(int argc, char** argv) {
     const int Bc = argc > 6 ? atoi(argv[6]) : B;
     const int L = 256, D = 128;
     srand(1);
-    auto fill = [&](std::vector<uint16_t>& img, std::vector<uint32_t>& mw, int n, double& toks) {
+    // "a<len>": every A sequence has <len> valid tokens, B sequences are full length
+    const int fixedA = (argc > 2 && argv[2][0] == 'a') ? atoi(argv[2] + 1) : 0;
+    auto fill = [&](std::vector<uint16_t>& img, std::vector<uint32_t>& mw, int n, double& toks, int fixed) {
         img.assign((size_t)n * L * D, 0); mw.assign((size_t)n * 8, 0); toks = 0;
         for (int s = 0; s < n; ++s) {
-            int len = full ? L : 128 + rand() % 129;
+            int len = fixed ? fixed : full ? L : 128 + rand() % 129;
             toks += len;
             for (int t = 0; t < len; ++t) {
                 mw[s * 8 + t / 32] |= 1u << (t % 32);
@@ -42,7 +44,7 @@ int main(int argc, char** argv) {
         }
     };
     std::vector<uint16_t> hA, hB; std::vector<uint32_t> mA, mB; double tokA, tokB;
-    fill(hA, mA, B, tokA); fill(hB, mB, Bc, tokB);
+    fill(hA, mA, B, tokA, fixedA); fill(hB, mB, Bc, tokB, fixedA ? L : 0);
     uint16_t *dA, *dB, *argA, *argB; uint32_t *dmA, *dmB; float *t, *sA, *sB;
     hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dmA, mA.size() * 4); hipMalloc(&dmB, mB.size() * 4);
     hipMalloc(&argA, (size_t)B * Bc * L * 2); hipMalloc(&argB, (size_t)B * Bc * L * 2);

@@ -344,27 +344,38 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
-    float runB = 0.f;  // emitter threads: running column sum of the sequence being streamed
-    const bool emitter = (tid == 0 || tid == 64);
-
     // Emits the two scores of every sequence whose last tile lies in epoch E (all of its parts
-    // are complete one barrier after that epoch's own).
+    // are complete one barrier after that epoch's own).  One wave does it — the last one when it
+    // holds no A tile, else the first (which the SIMD serves first) — with the LDS reads spread
+    // over its lanes: lane = (A sequence, tile of the epoch, A tile); lanes 0 and 32 then walk the
+    // epoch's tiles in order and keep the running column sum of the sequence being streamed.
+    static_assert(SE <= 4, "emit_epoch spreads at most four tiles of an epoch over the lanes");
+    float runB = 0.f;
+    const int emit_w = n_items < NW ? NW - 1 : 0;
     auto emit_epoch = [&](int E) {
-        const int em_isel = tid >> 6;
-        if (emitter && ISEQ(em_isel) >= 0) {
-            const int par = E % 3;
-            for (int q = 0; q < SE; ++q) {
-                const uint4 m = meta[E * SE + q];
-                if (m.w & FLAG_NULL) continue;
-                runB += colpart[(par * SE + q) * 2 + em_isel];
-                if (m.w & FLAG_LAST) {
-                    const int jl = m.z & 0xff;
-                    float sa = 0.f;
-                    for (int at = 0; at < 8; ++at)
-                        if (mwa_l[em_isel * 8 + at]) sa += rowp[(par * SE + q) * 16 + em_isel * 8 + at];
-                    const size_t o = (size_t)ISEQ(em_isel) * p.Bc + j_begin + jl;
-                    p.simA[o] = sa * scl_l[1 + em_isel] * scl_l[0];
-                    p.simB[o] = runB / fmaxf((float)nb_l[jl], 1e-6f) * scl_l[0];
+        if (w != emit_w) return;
+        const int par = E % 3;
+        const int e_isel = lane >> 5, e_q = min((lane >> 3) & 3, SE - 1), e_at = lane & 7;
+        float rs = mwa_l[e_isel * 8 + e_at] ? rowp[(par * SE + e_q) * 16 + e_isel * 8 + e_at] : 0.f;
+        rs += __shfl_xor(rs, 1);
+        rs += __shfl_xor(rs, 2);
+        rs += __shfl_xor(rs, 4);
+        const float cp = colpart[(par * SE + e_q) * 2 + e_isel];
+        const uint4 m = meta[E * SE + e_q];
+        const float nbv = fmaxf((float)nb_l[m.z & 0xff], 1e-6f);
+        const float sc0 = scl_l[0], scA = scl_l[1 + e_isel];
+        const bool head = (lane & 31) == 0 && ISEQ(e_isel) >= 0;
+#pragma unroll
+        for (int q = 0; q < SE; ++q) {
+            const int src = (lane & 32) + q * 8;
+            const float rs_q = __shfl(rs, src), cp_q = __shfl(cp, src), nb_q = __shfl(nbv, src);
+            const uint32_t fl_q = __shfl(m.w, src), z_q = __shfl(m.z, src);
+            if (head && !(fl_q & FLAG_NULL)) {
+                runB += cp_q;
+                if (fl_q & FLAG_LAST) {
+                    const size_t o = (size_t)ISEQ(e_isel) * p.Bc + j_begin + (int)(z_q & 0xff);
+                    p.simA[o] = rs_q * scA * sc0;
+                    p.simB[o] = runB / nb_q * sc0;
                     runB = 0.f;
                 }
             }
@@ -546,7 +557,10 @@ int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br,
 #ifdef STREAM_STAMPS
     a.dbg = g_stream_dbg;
 #endif
-    int nchunk = (1024 + a.ngroups - 1) / a.ngroups;   // about four workgroups per CU over the launch
+    #ifndef STREAM_WGS
+#define STREAM_WGS 1024
+#endif
+    int nchunk = (STREAM_WGS + a.ngroups - 1) / a.ngroups;   // about four workgroups per CU over the launch
     int jchunk = (Bc + nchunk - 1) / nchunk;
     if (jchunk < 8) jchunk = Bc < 8 ? Bc : 8;
     if (jchunk > SMAXJ) jchunk = SMAXJ;

@@ -39,7 +39,8 @@ extern "C" {
 /* limits of this build (checked, never silently exceeded) */
 #define PCLIP_CLIP_MAX_D 128     /* CLIP embedding width handled by the MFMA kernels      */
 #define PCLIP_FILIP_MAX_D 128    /* FILIP token embedding width (zero-padded to 128)      */
-#define PCLIP_FILIP_MAX_T 256    /* FILIP tokens per sequence handled by one LDS image    */
+#define PCLIP_FILIP_MAX_T 256    /* FILIP tokens per sequence handled by the fast kernels */
+#define PCLIP_FILIP_MAX_T_LONG 4096 /* FILIP tokens per sequence at most (general kernel)  */
 
 int pclip_version(void);
 const char* pclip_last_error(void);
@@ -144,7 +145,9 @@ int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, i
  * padding tokens are unspecified and may be left unwritten.  Pass NULL for both to skip them
  * in inference.)  Setting the environment variable PCLIP_FILIP_KERNEL=old before the call
  * selects the earlier non-streaming unit-norm kernel (kept for A/B timing).
- * TA, TB <= PCLIP_FILIP_MAX_T. */
+ * TA, TB <= PCLIP_FILIP_MAX_T_LONG; sequences beyond PCLIP_FILIP_MAX_T tokens (the reference keeps
+ * chains of up to 2,000 residues, modules/data_utils_2protein.py:88) run on a general, untuned
+ * kernel. */
 int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
                         const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,
                         const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void filip_sim_kernel(FilipArgs p) {
 
 // ---- host side -------------------------------------------------------------------------
 static int filip_dims_ok(const char* who, int B, int T, int d) {
-    PCLIP_REQUIRE(B >= 1 && T >= 1 && T <= PCLIP_FILIP_MAX_T, "%s: B=%d T=%d (need 1 <= T <= %d)", who, B, T, PCLIP_FILIP_MAX_T);
+    PCLIP_REQUIRE(B >= 1 && T >= 1 && T <= PCLIP_FILIP_MAX_T_LONG, "%s: B=%d T=%d (need 1 <= T <= %d)", who, B, T, PCLIP_FILIP_MAX_T_LONG);
     PCLIP_REQUIRE(d >= 1 && d <= PCLIP_FILIP_MAX_D, "%s: d=%d (need 1 <= d <= %d)", who, d, PCLIP_FILIP_MAX_D);
     return PCLIP_OK;
 }
@@ -299,6 +299,9 @@ extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, 
     PCLIP_REQUIRE((argA == nullptr) == (argB == nullptr), "filip_sim_fwd: pass both argA and argB or neither");
     if (int rc = filip_dims_ok("filip_sim_fwd", Br, TA, FD)) return rc;
     if (int rc = filip_dims_ok("filip_sim_fwd", Bc, TB, FD)) return rc;
+    if (TA > PCLIP_FILIP_MAX_T || TB > PCLIP_FILIP_MAX_T)
+        return filip_sim_long_launch(hnA, maskwA, Br, (TA + 31) / 32 * 32, hnB, maskwB, Bc, (TB + 31) / 32 * 32, t, sim_A, sim_B, argA, argB,
+                                     stream);
     if (unit_norm) {
         static const int which = [] { const char* e = getenv("PCLIP_FILIP_KERNEL"); return (e && e[0] == 'o') ? 0 : 1; }();
         if (which)

@@ -21,7 +21,7 @@
 
 #define FD 128
 #define BWD_XCDS 8          // windows per gather launch = partial gradients
-#define BWD_MAX_WINDOWS 128 // the counting sort keeps windows x 256 counters in LDS
+#define BWD_MAX_BUCKETS 32768 // the counting sort keeps windows x own tokens counters in LDS (128 KB)
 
 struct FilipBwdArgs {
     const uint16_t* hnP;   // partner images [Np][TPp][128] bf16
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(1024) void filip_invert_kernel(FilipBwdArgs p) {
     const int o = blockIdx.x;
     const int ntP = p.TPp >> 5;
     const int vpr = p.TPp >> 3;                          // 8-entry vectors per partner row
-    const int nbuck = p.nwt * PCLIP_FILIP_MAX_T;         // a multiple of 256
+    const int nbuck = p.nwt * p.TOp;
     const int per = (nbuck + 1023) >> 10;                // consecutive buckets per thread in the scan
     int* seg = p.seg + (size_t)o * (p.nwt * p.TOp + 1);
     for (int k = tid; k < nbuck; k += 1024) hist[k] = 0;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(1024) void filip_invert_kernel(FilipBwdArgs p) {
         if (m8 == 0) continue;
         const uint4 d = *reinterpret_cast<const uint4*>(p.arg2 + ((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt0);
         const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
-        int* hc = hist + (q / p.qpw) * PCLIP_FILIP_MAX_T;
+        int* hc = hist + (q / p.qpw) * p.TOp;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if ((m8 >> k) & 1u) atomicAdd(&hc[(dw[k >> 1] >> (16 * (k & 1))) & 0xffffu], 1);
@@ -110,9 +110,7 @@ __global__ __launch_bounds__(1024) void filip_invert_kernel(FilipBwdArgs p) {
             if (b >= nbuck) break;
             const int n = hist[b];
             hist[b] = run;
-            // counts of tokens >= TOp are zero, so their offsets equal the next stored one
-            const int x = b / PCLIP_FILIP_MAX_T, a = b - x * PCLIP_FILIP_MAX_T;
-            if (a < p.TOp) seg[x * p.TOp + a] = run;
+            seg[b] = run;
             run += n;
         }
         if (tid == 1023) seg[p.nwt * p.TOp] = run;
@@ -125,7 +123,7 @@ __global__ __launch_bounds__(1024) void filip_invert_kernel(FilipBwdArgs p) {
         if (m8 == 0) continue;
         const uint4 d = *reinterpret_cast<const uint4*>(p.arg2 + ((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt0);
         const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
-        int* hc = hist + (q / p.qpw) * PCLIP_FILIP_MAX_T;
+        int* hc = hist + (q / p.qpw) * p.TOp;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if ((m8 >> k) & 1u) {
@@ -252,7 +250,7 @@ static size_t bwd_window_bytes() {
     const long kb = e ? atol(e) : 0;
     return kb > 0 ? (size_t)kb << 10 : (size_t)2 << 20;
 }
-static BwdPlan bwd_plan(int Np, int TPp) {
+static BwdPlan bwd_plan(int Np, int TPp, int TOp) {
     const size_t per = (size_t)TPp * FD * 2, budget = bwd_window_bytes();
     BwdPlan pl;
     if ((size_t)Np * per <= budget || Np < BWD_XCDS) { pl.nwt = 1; pl.qpw = Np; return pl; }
@@ -260,8 +258,9 @@ static BwdPlan bwd_plan(int Np, int TPp) {
     if (qpw < 1) qpw = 1;
     int nwt = (Np + qpw - 1) / qpw;
     nwt = (nwt + BWD_XCDS - 1) / BWD_XCDS * BWD_XCDS;
-    if (nwt > BWD_MAX_WINDOWS) {
-        nwt = BWD_MAX_WINDOWS;
+    const int cap = BWD_MAX_BUCKETS / TOp / BWD_XCDS * BWD_XCDS;   // >= 8 for TOp <= PCLIP_FILIP_MAX_T_LONG
+    if (nwt > cap) {
+        nwt = cap;
         qpw = (Np + nwt - 1) / nwt;
     }
     pl.nwt = nwt; pl.qpw = qpw;
@@ -275,8 +274,8 @@ struct BwdWs {
 static BwdWs bwd_ws_layout(int Br, int TA, int Bc, int TB) {
     const size_t TAp = tp32(TA), TBp = tp32(TB);
     BwdWs w;
-    w.planA = bwd_plan(Bc, (int)TBp);
-    w.planB = bwd_plan(Br, (int)TAp);
+    w.planA = bwd_plan(Bc, (int)TBp, (int)TAp);
+    w.planB = bwd_plan(Br, (int)TAp, (int)TBp);
     size_t off = 0;
     w.listA = off; off += pclip_align_up((size_t)Br * Bc * TBp * 4, 256);   // buckets of B tokens per A sequence
     w.listB = off; off += pclip_align_up((size_t)Bc * Br * TAp * 4, 256);   // buckets of A tokens per B sequence
@@ -317,8 +316,8 @@ extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, 
     PCLIP_REQUIRE(hnA && maskwA && hnB && maskwB && t && sim_A && sim_B && argA && argB && gA && gB && dnA && dnB && dt && ws,
                   "filip_sim_bwd: null pointer");
     PCLIP_REQUIRE(Br >= 1 && Bc >= 1 && Br <= 65535 && Bc <= 65535, "filip_sim_bwd: Br=%d Bc=%d (need 1..65535)", Br, Bc);
-    PCLIP_REQUIRE(TA >= 1 && TA <= PCLIP_FILIP_MAX_T && TB >= 1 && TB <= PCLIP_FILIP_MAX_T, "filip_sim_bwd: TA=%d TB=%d (need 1..%d)", TA, TB,
-                  PCLIP_FILIP_MAX_T);
+    PCLIP_REQUIRE(TA >= 1 && TA <= PCLIP_FILIP_MAX_T_LONG && TB >= 1 && TB <= PCLIP_FILIP_MAX_T_LONG, "filip_sim_bwd: TA=%d TB=%d (need 1..%d)",
+                  TA, TB, PCLIP_FILIP_MAX_T_LONG);
     const BwdWs L = bwd_ws_layout(Br, TA, Bc, TB);
     PCLIP_REQUIRE(ws_bytes >= L.total, "filip_sim_bwd: workspace %zu < %zu bytes", ws_bytes, L.total);
     const int TAp = tp32(TA), TBp = tp32(TB);
@@ -338,8 +337,8 @@ extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, 
     b.arg1 = argB; b.arg2 = argA; b.g1 = gB; b.g2 = gA; b.so = 1; b.sp = (size_t)Bc; b.t = t;
     b.icO = icB; b.icP = icA; b.seg = (int*)(w + L.segB); b.list = (uint32_t*)(w + L.listB); b.dn = nullptr;
     b.nwt = L.planB.nwt; b.qpw = L.planB.qpw; b.win0 = 0; b.accumulate = 0;
-    const int nwt_max = a.nwt > b.nwt ? a.nwt : b.nwt;
-    const size_t hist_bytes = (size_t)nwt_max * PCLIP_FILIP_MAX_T * 4;
+    const size_t hA_bytes = (size_t)a.nwt * TAp * 4, hB_bytes = (size_t)b.nwt * TBp * 4;
+    const size_t hist_bytes = hA_bytes > hB_bytes ? hA_bytes : hB_bytes;
     if (hist_bytes > 48 * 1024) {
         static size_t raised = 0;
         if (hist_bytes > raised) {
@@ -348,10 +347,10 @@ extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, 
             raised = hist_bytes;
         }
     }
-    hipLaunchKernelGGL(filip_invert_kernel, dim3(Br), dim3(1024), (size_t)a.nwt * PCLIP_FILIP_MAX_T * 4, st, a);
+    hipLaunchKernelGGL(filip_invert_kernel, dim3(Br), dim3(1024), (size_t)a.nwt * TAp * 4, st, a);
     bwd_gather_side(a, (float*)(w + L.partA), dnA, st);
     if (int rc = pclip_check_launch("filip backward (A side)")) return rc;
-    hipLaunchKernelGGL(filip_invert_kernel, dim3(Bc), dim3(1024), (size_t)b.nwt * PCLIP_FILIP_MAX_T * 4, st, b);
+    hipLaunchKernelGGL(filip_invert_kernel, dim3(Bc), dim3(1024), (size_t)b.nwt * TBp * 4, st, b);
     bwd_gather_side(b, (float*)(w + L.partB), dnB, st);
     if (int rc = pclip_check_launch("filip backward (B side)")) return rc;
     const size_t n = (size_t)Br * Bc;

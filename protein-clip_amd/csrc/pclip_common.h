@@ -59,3 +59,6 @@ int filip_sim_unit_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
 // internal launcher of the streaming unit-norm FILIP score kernel (filip_stream.hip)
 int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
                             int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, void* stream);
+// internal launcher of the general FILIP score kernel for long sequences (filip_long.hip)
+int filip_sim_long_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
+                          int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, void* stream);

@@ -385,3 +385,30 @@ def test_filip_rank_shape_decomposes_over_partner_blocks(K):
         close(dnB[sl], db.cpu(), 1e-5, 1e-7)
     close(dnA, dnA_sum.cpu(), 1e-4, 1e-7)
     close(dt, dt_sum.cpu(), 1e-4, 1e-6)
+
+
+@pytest.mark.parametrize("TA,TB,normalise", [(300, 270, True), (40, 333, True), (290, 64, False)])
+def test_filip_sequences_beyond_one_lds_image(K, TA, TB, normalise):
+    """Chains longer than 256 tokens (the reference keeps up to 2,000 residues,
+    data_utils_2protein.py:88) run on the general kernel: scores, arg-max routing and the
+    backward against the oracle, ragged masks, one empty middle stretch."""
+    gen = torch.Generator().manual_seed(TA * 1000 + TB)
+    B, d = 3, 128
+    hA, hB = torch.randn(B, TA, d, generator=gen), torch.randn(B, TB, d, generator=gen)
+    mA = O.right_padded_masks(torch.randint(TA // 2, TA + 1, (B,), generator=gen), TA).clone()
+    mB = O.right_padded_masks(torch.randint(TB // 2, TB + 1, (B,), generator=gen), TB).clone()
+    mA[1, 30:70] = 0   # a whole tile of padding inside a sequence
+    t = torch.tensor(0.8)
+    gA, gB = torch.randn(B, B, generator=gen), torch.randn(B, B, generator=gen)
+    if not normalise:   # pre-normalised, bf16-exact operands through the raw entry
+        hA, hB = O.bf16_round(O.filip_normalise(hA)), O.bf16_round(O.filip_normalise(hB))
+    sA, sB, dA_ref, dB_ref, dt_ref = _oracle_filip_grads(hA, hB, mA, mB, t, normalise, gA, gB)
+    hnA, mwA, hnB, mwB, simA, simB, argA, argB = _filip_fwd(K, hA, hB, mA, mB, t, normalise=normalise)
+    close(simA, sA, 2e-6, 2e-6)
+    close(simB, sB, 2e-6, 2e-6)
+    dnA, dnB, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, dev(t.reshape(1)), simA, simB, argA, argB, dev(gA), dev(gB))
+    dA = K.filip_prep_bwd(dev(hA), dnA, normalise=normalise, tsign=dev(t.reshape(1)))
+    dB = K.filip_prep_bwd(dev(hB), dnB, normalise=normalise)
+    mostly_close(dA, dA_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)
+    mostly_close(dB, dB_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)
+    close(dt, dt_ref.reshape(1), 1e-4, 1e-5)

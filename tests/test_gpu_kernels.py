@@ -412,3 +412,51 @@ def test_filip_sequences_beyond_one_lds_image(K, TA, TB, normalise):
     mostly_close(dA, dA_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)
     mostly_close(dB, dB_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)
     close(dt, dt_ref.reshape(1), 1e-4, 1e-5)
+
+
+def test_filip_random_small_shapes_against_oracle(K):
+    """Seeded sweep over awkward shapes: batch sizes 1..19 (odd ones leave a workgroup with one A
+    sequence), token counts around the 32-token tile edges, narrow embeddings, random (not only
+    right-padded) masks with empty sequences on either side, both signs of the temperature,
+    Br != Bc.  Scores and gradients against the oracle."""
+    gen = torch.Generator().manual_seed(2024)
+    pick = lambda xs: xs[int(torch.randint(len(xs), (1,), generator=gen))]
+    for trial in range(24):
+        Br, Bc = pick([1, 2, 3, 5, 9, 19]), pick([1, 2, 3, 5, 9, 19])
+        TA, TB = pick([1, 5, 31, 32, 33, 64, 65, 100]), pick([1, 5, 31, 32, 33, 64, 65, 100])
+        d = pick([8, 20, 128])
+        normalise = trial % 3 != 2
+        t = torch.tensor(pick([1.0, 0.7, -0.9]))
+        hA, hB = torch.randn(Br, TA, d, generator=gen), torch.randn(Bc, TB, d, generator=gen)
+        mA = (torch.rand(Br, TA, generator=gen) > 0.3).to(torch.uint8)
+        mB = (torch.rand(Bc, TB, generator=gen) > 0.3).to(torch.uint8)
+        mA[:, 0] = 1
+        mB[:, 0] = 1
+        if trial % 4 == 1 and Bc > 1:
+            mB[Bc - 1] = 0          # an empty B sequence
+        if trial % 4 == 3 and Br > 1:
+            mA[0] = 0               # an empty A sequence
+        if not normalise:
+            hA, hB = O.bf16_round(O.filip_normalise(hA)), O.bf16_round(O.filip_normalise(hB))
+        gA, gB = torch.randn(Br, Bc, generator=gen), torch.randn(Br, Bc, generator=gen)
+        liveA, liveB = mA.sum(1) > 0, mB.sum(1) > 0
+        gA[:, ~liveB] = 0           # scores against an empty sequence are -inf / 0: keep them out of the sums
+        gB[:, ~liveB] = 0
+        gA[~liveA] = 0
+        gB[~liveA] = 0
+        sA, sB, dA_ref, dB_ref, dt_ref = _oracle_filip_grads(hA, hB, mA, mB, t, normalise, gA, gB)
+        hnA, mwA, hnB, mwB, simA, simB, argA, argB = _filip_fwd(K, hA, hB, mA, mB, t, normalise=normalise)
+        ok = liveA[:, None] & liveB[None, :]
+        tag = f"trial {trial}: Br={Br} Bc={Bc} TA={TA} TB={TB} d={d} normalise={normalise} t={float(t)}"
+        assert torch.allclose(simA.cpu()[ok], sA[ok], rtol=2e-6, atol=3e-6), tag
+        assert torch.allclose(simB.cpu()[ok], sB[ok], rtol=2e-6, atol=3e-6), tag
+        dnA, dnB, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, dev(t.reshape(1)), simA, simB, argA, argB, dev(gA), dev(gB))
+        dA = K.filip_prep_bwd(dev(hA), dnA, normalise=normalise, tsign=dev(t.reshape(1)))
+        dB = K.filip_prep_bwd(dev(hB), dnB, normalise=normalise)
+        try:
+            mostly_close(dA, dA_ref, 1e-3, 1e-6, max_bad_frac=0.02, max_rel_l2=0.05)
+            mostly_close(dB, dB_ref, 1e-3, 1e-6, max_bad_frac=0.02, max_rel_l2=0.05)
+        except AssertionError as exc:
+            raise AssertionError(f"{tag}: {exc}") from None
+        if bool(ok.all()):
+            assert torch.allclose(dt.cpu(), dt_ref.reshape(1), rtol=1e-4, atol=1e-5), tag

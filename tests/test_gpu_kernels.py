@@ -119,6 +119,25 @@ def test_clip_benchmark_size_scalars(K):
         assert radial < 1e-6
 
 
+def test_clip_random_shapes_against_oracle(K):
+    """Seeded sweep of the fused CLIP step over batch sizes around the 32-row tile edges and
+    embedding widths from 4 to 128, temperatures 0, 1, 2 and a peaked case."""
+    gen = torch.Generator().manual_seed(77)
+    pick = lambda xs: xs[int(torch.randint(len(xs), (1,), generator=gen))]
+    for trial in range(16):
+        B, d = pick([1, 2, 5, 31, 32, 33, 100, 257]), pick([4, 8, 64, 100, 128])
+        t = torch.tensor(pick([0.0, 1.0, 2.0]), dtype=torch.float64)
+        e_pep = torch.randn(B, d, generator=gen)
+        e_rec = e_pep + 0.1 * torch.randn(B, d, generator=gen) if trial % 2 else torch.randn(B, d, generator=gen)
+        ol, odp, odr, odt = O.clip_step_analytic(e_pep.double(), e_rec.double(), t)
+        loss, dp, dr, dt = K.clip_step(dev(e_pep), dev(e_rec), dev(t.float().reshape(1)))
+        tag = f"trial {trial}: B={B} d={d} t={float(t)}"
+        assert torch.allclose(loss.cpu().double(), ol.reshape(1), rtol=2e-5, atol=2e-6), tag
+        assert torch.allclose(dp.cpu().double(), odp, rtol=2e-4, atol=1e-6), tag
+        assert torch.allclose(dr.cpu().double(), odr, rtol=2e-4, atol=1e-6), tag
+        assert torch.allclose(dt.cpu().double(), odt.reshape(1), rtol=2e-4, atol=5e-6), tag
+
+
 def test_clip_sharded_rows_equal_single_device(K):
     """Two 'ranks' each owning half the rows reproduce the one-device result exactly as the
     multi-GPU path assembles it: lse vectors concatenated, loss parts summed."""

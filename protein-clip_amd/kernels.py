@@ -175,7 +175,13 @@ def filip_prep(h, mask, normalise: bool, tsign=None):
     is negative (pass the temperature on the A side)."""
     require_gpu_tensor(h, F32, "h")
     B, T, d = h.shape
-    m8 = (mask != 0).to(torch.uint8).contiguous()
+    # the kernel reads one byte per token and treats any nonzero byte as valid (as .bool() does)
+    if mask.dtype == torch.uint8:
+        m8 = mask.contiguous()
+    elif mask.dtype == torch.bool:
+        m8 = mask.contiguous().view(torch.uint8)
+    else:
+        m8 = (mask != 0).to(torch.uint8).contiguous()
     if m8.shape != (B, T) or not m8.is_cuda:
         raise _lib.PclipError("filip_prep: mask must be a GPU tensor of shape [B,T]")
     Tp = _tp(T)

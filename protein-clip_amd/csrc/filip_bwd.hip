@@ -21,7 +21,6 @@
 
 #define FD 128
 #define BWD_XCDS 8          // windows per gather launch = partial gradients
-#define BWD_MAX_BUCKETS 32768 // the counting sort keeps windows x own tokens counters in LDS (128 KB)
 
 struct FilipBwdArgs {
     const uint16_t* hnP;   // partner images [Np][TPp][128] bf16
@@ -36,8 +35,9 @@ struct FilipBwdArgs {
     const float* t;
     const float* icO;      // [No] 1/max(valid own tokens, 1e-6), 0 where the sequence is empty
     const float* icP;      // [Np] same for partners
-    int* seg;              // [No][nwt*TOp+1] bucket offsets, index = window*TOp + own token
-    uint32_t* list;        // [No][Np*TPp] bucketed entries (partner << 16 | partner token)
+    int* seg;              // [No][nwt][TOp+1] bucket offsets inside the window's list
+    uint32_t* list;        // [No][Np*TPp] bucketed entries (partner << 16 | partner token); window x of a
+                           // sequence starts at entry x*qpw*TPp of its region
     float* dn;             // [nslot][No][TOp][128] f32 out: partial gradients (nslot = min(nwt, 8))
     int nwt, qpw;          // partner windows in total (1, or a multiple of 8), partners per window
     int win0, accumulate;  // gather launch: first window it covers; add to the partials instead of overwriting
@@ -59,42 +59,47 @@ __global__ __launch_bounds__(256) void filip_count_kernel(const uint32_t* __rest
     ic[s] = c > 0 ? 1.f / (float)c : 0.f;
 }
 
-// One workgroup (16 waves) per own sequence: counting sort of the valid partner tokens by
-// (partner window, own token they chose).  Eight u16 entries are read per 16-byte load.
-// Dynamic LDS: nwt * 256 counters.  (The two sides run as two launches: one launch holding
-// both measured 9 % slower than the pair — the kernel is bound by its scattered 4-byte list
-// stores, not by latency.)
-__global__ __launch_bounds__(1024) void filip_invert_kernel(FilipBwdArgs p) {
-    extern __shared__ int hist[];                        // [window][own token] counts, then bucket cursors
-    __shared__ int wsum[16];
+// One workgroup per (own sequence, partner window): counting sort of the window's valid partner
+// tokens by the own token they chose.  Eight u16 entries are read per 16-byte load; the sorted
+// entries are built in LDS and leave as one coalesced copy (scattered 4-byte stores to global
+// memory made the earlier one-workgroup-per-sequence form four times slower); a window too
+// large for the LDS stage scatters straight to global memory instead.
+// Dynamic LDS: TOp counters, then `stage` entries.
+#define INV_THREADS 512
+#define INV_STAGE_MAX 24576   // entries (96 KB)
+__global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs p, int stage) {
+    extern __shared__ int hist[];                        // [own token] counts, then bucket cursors
+    __shared__ int wsum[INV_THREADS / 64];
+    uint32_t* sorted = reinterpret_cast<uint32_t*>(hist + p.TOp);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int o = blockIdx.x;
+    const int o = blockIdx.x / p.nwt, x = blockIdx.x - o * p.nwt;
+    const int q_lo = x * p.qpw, q_hi = min(p.Np, q_lo + p.qpw);
     const int ntP = p.TPp >> 5;
     const int vpr = p.TPp >> 3;                          // 8-entry vectors per partner row
-    const int nbuck = p.nwt * p.TOp;
-    const int per = (nbuck + 1023) >> 10;                // consecutive buckets per thread in the scan
-    int* seg = p.seg + (size_t)o * (p.nwt * p.TOp + 1);
-    for (int k = tid; k < nbuck; k += 1024) hist[k] = 0;
+    const int per = (p.TOp + INV_THREADS - 1) / INV_THREADS;   // consecutive buckets per thread in the scan
+    int* seg = p.seg + ((size_t)o * p.nwt + x) * (p.TOp + 1);
+    uint32_t* list = p.list + (size_t)o * p.Np * p.TPp + (size_t)q_lo * p.TPp;
+    for (int k = tid; k < p.TOp; k += INV_THREADS) hist[k] = 0;
     __syncthreads();
     const bool own_live = p.icO[o] > 0.f;
-    const int nvec = own_live ? p.Np * vpr : 0;
-    for (int v = tid; v < nvec; v += 1024) {
-        const int q = v / vpr, pt0 = (v - q * vpr) * 8;
+    const int nvec = (own_live && q_hi > q_lo) ? (q_hi - q_lo) * vpr : 0;
+    for (int v = tid; v < nvec; v += INV_THREADS) {
+        const int ql = v / vpr, pt0 = (v - ql * vpr) * 8, q = q_lo + ql;
         const uint32_t m8 = (p.mwP[(size_t)q * ntP + (pt0 >> 5)] >> (pt0 & 31)) & 0xffu;
         if (m8 == 0) continue;
         const uint4 d = *reinterpret_cast<const uint4*>(p.arg2 + ((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt0);
         const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
-        int* hc = hist + (q / p.qpw) * p.TOp;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if ((m8 >> k) & 1u) atomicAdd(&hc[(dw[k >> 1] >> (16 * (k & 1))) & 0xffffu], 1);
+            if ((m8 >> k) & 1u) atomicAdd(&hist[(dw[k >> 1] >> (16 * (k & 1))) & 0xffffu], 1);
     }
     __syncthreads();
-    {   // exclusive scan of the counts in (window, token) order, `per` consecutive ones per thread
+    int total;
+    {   // exclusive scan of the counts, `per` consecutive ones per thread
         const int b0 = tid * per;
         int s = 0;
         for (int k = 0; k < per; ++k)
-            if (b0 + k < nbuck) s += hist[b0 + k];
+            if (b0 + k < p.TOp) s += hist[b0 + k];
         int incl = s;
 #pragma unroll
         for (int o2 = 1; o2 < 64; o2 <<= 1) {
@@ -104,32 +109,39 @@ __global__ __launch_bounds__(1024) void filip_invert_kernel(FilipBwdArgs p) {
         if (lane == 63) wsum[w] = incl;
         __syncthreads();
         int run = incl - s;
-        for (int k = 0; k < w; ++k) run += wsum[k];
+        total = 0;
+        for (int k = 0; k < INV_THREADS / 64; ++k) {
+            if (k < w) run += wsum[k];
+            total += wsum[k];
+        }
         for (int k = 0; k < per; ++k) {
             const int b = b0 + k;
-            if (b >= nbuck) break;
+            if (b >= p.TOp) break;
             const int n = hist[b];
             hist[b] = run;
             seg[b] = run;
             run += n;
         }
-        if (tid == 1023) seg[p.nwt * p.TOp] = run;
+        if (tid == 0) seg[p.TOp] = total;
     }
     __syncthreads();
-    uint32_t* list = p.list + (size_t)o * p.Np * p.TPp;
-    for (int v = tid; v < nvec; v += 1024) {
-        const int q = v / vpr, pt0 = (v - q * vpr) * 8;
+    uint32_t* dst = stage ? sorted : list;   // LDS stage or straight to global memory
+    for (int v = tid; v < nvec; v += INV_THREADS) {
+        const int ql = v / vpr, pt0 = (v - ql * vpr) * 8, q = q_lo + ql;
         const uint32_t m8 = (p.mwP[(size_t)q * ntP + (pt0 >> 5)] >> (pt0 & 31)) & 0xffu;
         if (m8 == 0) continue;
         const uint4 d = *reinterpret_cast<const uint4*>(p.arg2 + ((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt0);
         const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
-        int* hc = hist + (q / p.qpw) * p.TOp;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if ((m8 >> k) & 1u) {
-                const int pos = atomicAdd(&hc[(dw[k >> 1] >> (16 * (k & 1))) & 0xffffu], 1);
-                list[pos] = ((uint32_t)q << 16) | (uint32_t)(pt0 + k);
+                const int pos = atomicAdd(&hist[(dw[k >> 1] >> (16 * (k & 1))) & 0xffffu], 1);
+                dst[pos] = ((uint32_t)q << 16) | (uint32_t)(pt0 + k);
             }
+    }
+    if (stage) {
+        __syncthreads();
+        for (int k = tid; k < total; k += INV_THREADS) list[k] = sorted[k];
     }
 }
 
@@ -182,8 +194,8 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
                 for (int e = 0; e < 8; ++e) acc[e] += ws[k] * (float)rows[k][e];
         }
         // partner-side max terms of this window that chose this token: its bucket of the sorted list
-        const int* seg = p.seg + (size_t)o * (p.nwt * p.TOp + 1) + x * p.TOp + a;
-        const uint32_t* list = p.list + (size_t)o * p.Np * p.TPp;
+        const int* seg = p.seg + ((size_t)o * p.nwt + x) * (p.TOp + 1) + a;
+        const uint32_t* list = p.list + (size_t)o * p.Np * p.TPp + (size_t)q_lo * p.TPp;
         const int end = seg[1];
         for (int pos0 = seg[0]; pos0 < end; pos0 += 16) {
             const int pos = pos0 + l16;
@@ -250,7 +262,7 @@ static size_t bwd_window_bytes() {
     const long kb = e ? atol(e) : 0;
     return kb > 0 ? (size_t)kb << 10 : (size_t)2 << 20;
 }
-static BwdPlan bwd_plan(int Np, int TPp, int TOp) {
+static BwdPlan bwd_plan(int Np, int TPp) {
     const size_t per = (size_t)TPp * FD * 2, budget = bwd_window_bytes();
     BwdPlan pl;
     if ((size_t)Np * per <= budget || Np < BWD_XCDS) { pl.nwt = 1; pl.qpw = Np; return pl; }
@@ -258,11 +270,6 @@ static BwdPlan bwd_plan(int Np, int TPp, int TOp) {
     if (qpw < 1) qpw = 1;
     int nwt = (Np + qpw - 1) / qpw;
     nwt = (nwt + BWD_XCDS - 1) / BWD_XCDS * BWD_XCDS;
-    const int cap = BWD_MAX_BUCKETS / TOp / BWD_XCDS * BWD_XCDS;   // >= 8 for TOp <= PCLIP_FILIP_MAX_T_LONG
-    if (nwt > cap) {
-        nwt = cap;
-        qpw = (Np + nwt - 1) / nwt;
-    }
     pl.nwt = nwt; pl.qpw = qpw;
     return pl;
 }
@@ -274,13 +281,13 @@ struct BwdWs {
 static BwdWs bwd_ws_layout(int Br, int TA, int Bc, int TB) {
     const size_t TAp = tp32(TA), TBp = tp32(TB);
     BwdWs w;
-    w.planA = bwd_plan(Bc, (int)TBp, (int)TAp);
-    w.planB = bwd_plan(Br, (int)TAp, (int)TBp);
+    w.planA = bwd_plan(Bc, (int)TBp);
+    w.planB = bwd_plan(Br, (int)TAp);
     size_t off = 0;
     w.listA = off; off += pclip_align_up((size_t)Br * Bc * TBp * 4, 256);   // buckets of B tokens per A sequence
     w.listB = off; off += pclip_align_up((size_t)Bc * Br * TAp * 4, 256);   // buckets of A tokens per B sequence
-    w.segA = off;  off += pclip_align_up((size_t)Br * (w.planA.nwt * TAp + 1) * 4, 256);
-    w.segB = off;  off += pclip_align_up((size_t)Bc * (w.planB.nwt * TBp + 1) * 4, 256);
+    w.segA = off;  off += pclip_align_up((size_t)Br * w.planA.nwt * (TAp + 1) * 4, 256);
+    w.segB = off;  off += pclip_align_up((size_t)Bc * w.planB.nwt * (TBp + 1) * 4, 256);
     w.icA = off;   off += pclip_align_up((size_t)Br * 4, 256);
     w.icB = off;   off += pclip_align_up((size_t)Bc * 4, 256);
     w.partA = off; off += w.planA.nwt > 1 ? pclip_align_up((size_t)BWD_XCDS * Br * TAp * FD * 4, 256) : 0;   // partials of dnA
@@ -337,22 +344,23 @@ extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, 
     b.arg1 = argB; b.arg2 = argA; b.g1 = gB; b.g2 = gA; b.so = 1; b.sp = (size_t)Bc; b.t = t;
     b.icO = icB; b.icP = icA; b.seg = (int*)(w + L.segB); b.list = (uint32_t*)(w + L.listB); b.dn = nullptr;
     b.nwt = L.planB.nwt; b.qpw = L.planB.qpw; b.win0 = 0; b.accumulate = 0;
-    const size_t hA_bytes = (size_t)a.nwt * TAp * 4, hB_bytes = (size_t)b.nwt * TBp * 4;
-    const size_t hist_bytes = hA_bytes > hB_bytes ? hA_bytes : hB_bytes;
-    if (hist_bytes > 48 * 1024) {
-        static size_t raised = 0;
-        if (hist_bytes > raised) {
-            if (hipFuncSetAttribute((const void*)filip_invert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes) != hipSuccess)
-                return pclip_fail(PCLIP_ELAUNCH, "filip_invert_kernel: cannot raise the dynamic LDS limit");
-            raised = hist_bytes;
+    for (int side = 0; side < 2; ++side) {
+        const FilipBwdArgs& u = side == 0 ? a : b;
+        const size_t cap = (size_t)u.qpw * u.TPp;                       // entries of one window at most
+        const int stage = cap <= INV_STAGE_MAX ? (int)cap : 0;
+        const size_t lds = ((size_t)u.TOp + stage) * 4;
+        if (lds > 48 * 1024) {
+            static size_t raised = 0;
+            if (lds > raised) {
+                if (hipFuncSetAttribute((const void*)filip_invert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                    return pclip_fail(PCLIP_ELAUNCH, "filip_invert_kernel: cannot raise the dynamic LDS limit");
+                raised = lds;
+            }
         }
+        hipLaunchKernelGGL(filip_invert_kernel, dim3((unsigned)((size_t)u.No * u.nwt)), dim3(INV_THREADS), lds, st, u, stage);
+        bwd_gather_side(u, (float*)(w + (side == 0 ? L.partA : L.partB)), side == 0 ? dnA : dnB, st);
+        if (int rc = pclip_check_launch(side == 0 ? "filip backward (A side)" : "filip backward (B side)")) return rc;
     }
-    hipLaunchKernelGGL(filip_invert_kernel, dim3(Br), dim3(1024), (size_t)a.nwt * TAp * 4, st, a);
-    bwd_gather_side(a, (float*)(w + L.partA), dnA, st);
-    if (int rc = pclip_check_launch("filip backward (A side)")) return rc;
-    hipLaunchKernelGGL(filip_invert_kernel, dim3(Bc), dim3(1024), (size_t)b.nwt * TBp * 4, st, b);
-    bwd_gather_side(b, (float*)(w + L.partB), dnB, st);
-    if (int rc = pclip_check_launch("filip backward (B side)")) return rc;
     const size_t n = (size_t)Br * Bc;
     const int blocks = (int)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
     hipLaunchKernelGGL(filip_dt_kernel, dim3(blocks), dim3(256), 0, st, gA, gB, sim_A, sim_B, n, t, dt);

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
     const bool valid = (p.mwO[(size_t)o * (p.TOp >> 5) + (a >> 5)] >> (a & 31)) & 1u;
     float4* out = reinterpret_cast<float4*>(p.dn + (((size_t)slot * p.No + o) * p.TOp + a) * FD + l16 * 8);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.accumulate) {
+    if (p.accumulate && valid) {
         const float4 u = out[0], v = out[1];
         acc[0] = u.x; acc[1] = u.y; acc[2] = u.z; acc[3] = u.w;
         acc[4] = v.x; acc[5] = v.y; acc[6] = v.z; acc[7] = v.w;
@@ -220,18 +220,26 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
                 for (int e = 0; e < 8; ++e) acc[e] += ws[k] * (float)rows[k][e];
         }
     }
+    if (!valid && p.nwt > 1) return;   // the window sum writes the zero rows of padding tokens itself
     out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
-// out = sum of the nslot partial gradients (n4 float4 each)
-__global__ __launch_bounds__(256) void filip_window_sum_kernel(const float4* __restrict__ part, size_t n4, int nslot, float4* __restrict__ out) {
+// out = sum of the nslot partial gradients (n4 float4 each); rows of padding tokens (never
+// written by the gather) are zero.
+__global__ __launch_bounds__(256) void filip_window_sum_kernel(const float4* __restrict__ part, size_t n4, int nslot, float4* __restrict__ out,
+                                                               const uint32_t* __restrict__ mwO, int TOp) {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n4) return;
-    float4 s = part[k];
-    for (int x = 1; x < nslot; ++x) {
-        const float4 v = part[(size_t)x * n4 + k];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    const size_t row = k / (FD / 4);
+    const int o = (int)(row / TOp), a = (int)(row - (size_t)o * TOp);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((mwO[(size_t)o * (TOp >> 5) + (a >> 5)] >> (a & 31)) & 1u) {
+        s = part[k];
+        for (int x = 1; x < nslot; ++x) {
+            const float4 v = part[(size_t)x * n4 + k];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
     out[k] = s;
 }
@@ -312,7 +320,7 @@ static void bwd_gather_side(FilipBwdArgs a, float* part, float* dn, hipStream_t 
     }
     if (a.nwt > 1) {
         const size_t n4 = (size_t)a.No * a.TOp * FD / 4;
-        hipLaunchKernelGGL(filip_window_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float4*)part, n4, nslot, (float4*)dn);
+        hipLaunchKernelGGL(filip_window_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float4*)part, n4, nslot, (float4*)dn, a.mwO, a.TOp);
     }
 }
 

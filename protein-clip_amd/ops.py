@@ -22,6 +22,15 @@ import torch.distributed as dist
 from . import kernels as _hip_kernels
 
 
+# Tests set this to run every collective in a one-rank process group as well (the GPU box has
+# one GPU; RCCL accepts a group of one), so that dtypes and shapes meet the real backend.
+FORCE_COLLECTIVES = False
+
+
+def _collective(world: int) -> bool:
+    return world > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
 def _world(group):
     if group is None and not (dist.is_available() and dist.is_initialized()):
         return 1, 0
@@ -30,10 +39,16 @@ def _world(group):
 
 def _all_gather_rows(t: torch.Tensor, group, world: int) -> torch.Tensor:
     """[n, ...] on every rank -> [world*n, ...], rank-major (rank r's rows at r*n)."""
-    if world == 1:
+    if not _collective(world):
         return t
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    src = t.contiguous()
+    if t.dtype in (torch.float32, torch.float64, torch.float16, torch.bfloat16):
+        dist.all_gather_into_tensor(out, src, group=group)
+    else:
+        # a gather only moves bytes, and RCCL has no 16-bit integer type (the bf16 images travel
+        # as int16 bit patterns): send every integer tensor as bytes
+        dist.all_gather_into_tensor(out.view(torch.uint8), src.view(torch.uint8), group=group)
     return out
 
 
@@ -76,7 +91,7 @@ class _ClipLoss(torch.autograd.Function):
         y_all = _all_gather_rows(y, group, world)
         off = rank * Bl
         lse_r, lse_c, loss, _ = K.clip_fwd(x, y, x_all, y_all, off)
-        if world > 1:
+        if _collective(world):
             # both log-sum-exp vectors travel in one collective: [2,Bl] per rank -> [world,2,Bl]
             both = torch.stack([lse_r, lse_c])
             gathered = _all_gather_rows(both, group, world).view((world,) + tuple(both.shape))
@@ -122,7 +137,7 @@ class _RowCE(torch.autograd.Function):
         logits = logits.contiguous()
         lse, loss = K.rowce_fwd(logits, row_offset, Bg, use_dcl)
         world, _ = _world(group)
-        if world > 1:
+        if _collective(world):
             dist.all_reduce(loss, group=group)
         ctx.K, ctx.cfg = K, (use_dcl, row_offset, Bg)
         ctx.save_for_backward(logits, lse)
@@ -173,7 +188,7 @@ class _FilipSim(torch.autograd.Function):
         K = ctx.K
         dnA, dnB_all, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA.contiguous(),
                                           gB.contiguous())
-        if world > 1:
+        if _collective(world):
             # every rank holds a partial gradient for every B sequence: sum and hand each rank its own
             dnB = torch.empty((hB.shape[0],) + tuple(dnB_all.shape[1:]), dtype=dnB_all.dtype, device=dnB_all.device)
             dist.reduce_scatter_tensor(dnB, dnB_all, group=group)

@@ -21,6 +21,15 @@ import torch.distributed as dist
 from . import kernels as _hip_kernels
 
 
+# Tests set this to run every collective in a one-rank process group as well (the GPU box has
+# one GPU; RCCL accepts a group of one), so that dtypes and shapes meet the real backend.
+FORCE_COLLECTIVES = False
+
+
+def _collective(world: int) -> bool:
+    return world > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
 def _world(group):
     if group is None and not (dist.is_available() and dist.is_initialized()):
         return 1, 0
@@ -28,11 +37,17 @@ def _world(group):
 
 
 def _gather(t, group, world):
-    if world == 1:
+    if not _collective(world):
         return t
     # concatenated-along-dim-0 output is the layout every backend (RCCL, gloo) accepts
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    src = t.contiguous()
+    if t.dtype in (torch.float32, torch.float64, torch.float16, torch.bfloat16):
+        dist.all_gather_into_tensor(out, src, group=group)
+    else:
+        # a gather only moves bytes, and RCCL has no 16-bit integer type (the bf16 images travel
+        # as int16 bit patterns): send every integer tensor as bytes
+        dist.all_gather_into_tensor(out.view(torch.uint8), src.view(torch.uint8), group=group)
     return out.view((world,) + tuple(t.shape))
 
 
@@ -48,7 +63,7 @@ class ClipShardedStep:
         Bl, d = e_pep.shape
         x = K.l2norm_scale_fwd(e_pep, t)
         y = K.l2norm_scale_fwd(e_rec, t)
-        if W > 1:
+        if _collective(W):
             both = _gather(torch.stack([x, y]), self.group, W)       # [W,2,Bl,d]
             x_all = both[:, 0].reshape(W * Bl, d).contiguous()
             y_all = both[:, 1].reshape(W * Bl, d).contiguous()
@@ -56,7 +71,7 @@ class ClipShardedStep:
             x_all, y_all = x, y
         off = self.rank * Bl
         lse_r, lse_c, loss, _ = K.clip_fwd(x, y, x_all, y_all, off)
-        if W > 1:
+        if _collective(W):
             lse = _gather(torch.stack([lse_r, lse_c]), self.group, W)  # [W,2,Bl]
             lse_r_all = lse[:, 0].reshape(-1).contiguous()
             lse_c_all = lse[:, 1].reshape(-1).contiguous()
@@ -65,7 +80,7 @@ class ClipShardedStep:
         dX, dY = K.clip_bwd(x, y, x_all, y_all, lse_r_all, lse_c_all, off)
         de_pep, dt = K.l2norm_scale_bwd(e_pep, t, dX)
         de_rec, dt = K.l2norm_scale_bwd(e_rec, t, dY, dt=dt)
-        if W > 1:
+        if _collective(W):
             pack = torch.cat([loss.reshape(1), dt.reshape(1)])
             dist.all_reduce(pack, group=self.group)
             loss, dt = pack[0:1], pack[1:2]
@@ -86,7 +101,7 @@ class FilipShardedStep:
         Bg = W * Bl
         hnA, mwA = K.filip_prep(hA, maskA, True, tsign=t)
         hnB, mwB = K.filip_prep(hB, maskB, True)
-        if W > 1:
+        if _collective(W):
             hnB_all = _gather(hnB, self.group, W).reshape((Bg,) + tuple(hnB.shape[1:]))
             mwB_all = _gather(mwB, self.group, W).reshape((Bg,) + tuple(mwB.shape[1:]))
         else:
@@ -102,7 +117,7 @@ class FilipShardedStep:
         gA = K.rowce_bwd(simA, lseA, off, Bg, False, gscale=0.5)
         gB = K.rowce_bwd(simB, lseB, off, Bg, False, gscale=0.5)
         dnA, dnB_all, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB)
-        if W > 1:
+        if _collective(W):
             dnB = torch.empty((Bl,) + tuple(dnB_all.shape[1:]), dtype=dnB_all.dtype, device=dnB_all.device)
             dist.reduce_scatter_tensor(dnB, dnB_all, group=self.group)
         else:
@@ -110,7 +125,7 @@ class FilipShardedStep:
         dhA = K.filip_prep_bwd(hA, dnA, True, tsign=t)
         dhB = K.filip_prep_bwd(hB, dnB, True)
         pack = torch.cat([lossA.reshape(1), lossB.reshape(1), dt.reshape(1)])
-        if W > 1:
+        if _collective(W):
             dist.all_reduce(pack, group=self.group)
         loss = (pack[0:1] + pack[1:2]) * 0.5
         self.last = {"simA": simA, "simB": simB}

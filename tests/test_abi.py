@@ -52,6 +52,6 @@ def test_bad_arguments_are_rejected_before_launch(lib):
     assert lib.pclip_clip_fwd(one, one, one, one, 8, 4, 128, 0, one, one, one, None, 0, one, 1 << 20, None) == -1   # Br > Bg
     assert lib.pclip_clip_fwd(one, one, one, one, 8, 8, 128, 0, one, one, one, None, 0, one, 16, None) == -1        # workspace too small
     assert b"workspace" in lib.pclip_last_error()
-    assert lib.pclip_filip_prep(one, one, 4, 300, 128, 1, None, one, one, None) == -1                                 # T > 256
+    assert lib.pclip_filip_prep(one, one, 4, 5000, 128, 1, None, one, one, None) == -1                                # T > 4096
     assert lib.pclip_filip_prep(one, one, 4, 64, 129, 1, None, one, one, None) == -1                                  # d > 128
     assert lib.pclip_rowce_fwd(one, 8, 4, 0, 8, 0, one, one, None) == -1                                              # target column out of range

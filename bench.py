@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["both", "clip", "filip"], default="both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="one GPU, but through the multi-rank code: a one-rank RCCL group, the sharded steps with every "
+                         "collective issued, the per-rank shapes of an N>1 run (not a benchmark result)")
     return ap.parse_args()
 
 
@@ -103,8 +106,17 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    rehearse = args.rehearse_dist and world == 1
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
+    elif rehearse:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+        from protein_clip_amd import steps as _steps
+        _steps.FORCE_COLLECTIVES = True
 
     from protein_clip_amd import _lib, kernels as K
     from protein_clip_amd.steps import ClipShardedStep, FilipShardedStep
@@ -112,13 +124,14 @@ def main():
     if lib.pclip_check_device(local_rank) != 0:
         raise SystemExit(lib.pclip_last_error().decode())
 
-    clip_bl = 256 if world == 1 else 1024
+    multi = world > 1 or rehearse          # the multi-rank code paths and shapes
+    clip_bl = 1024 if multi else 256
     filip_bl = 256
     cpu, dv = make_inputs(rank, clip_bl, filip_bl, device)
     t = torch.tensor([1.0], device=device)
 
-    clip_fused = K.ClipStep(clip_bl, D, device) if world == 1 else None
-    clip_sh = ClipShardedStep() if world > 1 else None
+    clip_fused = None if multi else K.ClipStep(clip_bl, D, device)
+    clip_sh = ClipShardedStep() if multi else None
     filip_sh = FilipShardedStep()
 
     def clip_step():
@@ -132,17 +145,17 @@ def main():
     def bracket(fn, steps):
         """Barrier + sync, run, sync + barrier; returns seconds (max over ranks)."""
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
             fn(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             tt = torch.tensor([el], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = tt.item()
@@ -170,7 +183,7 @@ def main():
     # secondary: the score kernel alone on full-length sequences (all 256 tokens valid), the
     # shape on which its distance from the MFMA peak is cleanest to read (no padding effects)
     full_ms = None
-    if do_filip and world == 1:
+    if do_filip and not multi:
         ones = torch.ones(filip_bl, L, dtype=torch.uint8, device=device)
         hnA_f, mwA_f = K.filip_prep(dv["hA"], ones, True, tsign=t)
         hnB_f, mwB_f = K.filip_prep(dv["hB"], ones, True)
@@ -192,7 +205,7 @@ def main():
     if do_filip:
         nA = int(cpu["lA"].sum())
         nB_local = torch.tensor([float(cpu["lB"].sum())], device=device, dtype=torch.float64)
-        if world > 1:
+        if multi:
             dist.all_reduce(nB_local)
         flops = 2.0 * D * nA * nB_local.item()
         achieved = flops / (sim_ms * 1e-3) / 1e12
@@ -251,10 +264,12 @@ def main():
             "roofline": roof,
             "workloads": workloads,
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "both":
+        if rehearse:
+            out["note"] = "rehearsal of the multi-rank code on one GPU (--rehearse-dist); not a benchmark result"
+        if not multi and not args.no_cpu_baseline and args.workload == "both":
             out["cpu_baseline"] = cpu_baseline(cpu, clip_bl, filip_bl)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

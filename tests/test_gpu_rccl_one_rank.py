@@ -73,3 +73,19 @@ def test_autograd_operators_through_rccl_equal_the_local_path(one_rank_group):
         ops.FORCE_COLLECTIVES = True
     for a, b in zip(got, ref):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_bench_multi_rank_path_rehearsal():
+    """bench.py through its N>1 code (process group, barriers, sharded steps with every
+    collective, max-over-ranks timing) in a one-rank RCCL group, as a child process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--rehearse-dist"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["config"]["clip_global_batch"] == 1024 and out["value"] > 0 and "rehearsal" in out["note"]

@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["both", "clip", "filip"], default="both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-length", action="store_true",
+                    help="also time the score kernel alone with every token valid (secondary record; off by default so that a "
+                         "profiler trace of the default command holds launches of the benchmark shape only)")
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="one GPU, but through the multi-rank code: a one-rank RCCL group, the sharded steps with every "
                          "collective issued, the per-rank shapes of an N>1 run (not a benchmark result)")
@@ -183,7 +186,7 @@ def main():
     # secondary: the score kernel alone on full-length sequences (all 256 tokens valid), the
     # shape on which its distance from the MFMA peak is cleanest to read (no padding effects)
     full_ms = None
-    if do_filip and not multi:
+    if do_filip and not multi and args.full_length:
         ones = torch.ones(filip_bl, L, dtype=torch.uint8, device=device)
         hnA_f, mwA_f = K.filip_prep(dv["hA"], ones, True, tsign=t)
         hnB_f, mwB_f = K.filip_prep(dv["hB"], ones, True)

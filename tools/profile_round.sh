@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 timeout -k 10 600 python3 -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > "$OUT/pytest_gpu.log" 2>&1 || { tail -30 "$OUT/pytest_gpu.log"; exit 1; }
 tail -3 "$OUT/pytest_gpu.log"
 
-timeout -k 10 600 python3 bench.py --steps "$STEPS" --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -30 "$OUT/bench.err"; exit 1; }
+timeout -k 10 600 python3 bench.py --steps "$STEPS" --warmup 5 --full-length > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -30 "$OUT/bench.err"; exit 1; }
 cat "$OUT/bench.json"
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps "$STEPS" --warmup 5 --no-cpu-baseline > "$OUT/trace.log" 2>&1 || { tail -30 "$OUT/trace.log"; exit 1; }

@@ -32,7 +32,7 @@ def short(name):
     return name.replace("void ", "").strip()
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:

@@ -117,6 +117,17 @@ int pclip_rowce_bwd(const float* logits, const float* lse, int Br, int Bc, int r
                     int use_dcl, const float* g, float gscale, float* dlogits, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Masked mean over tokens.  Replaces Encoder._masked_mean (modules/models.py:76-90), the
+ * pooling in front of the embedding head of each CLIP tower (models.py:48):
+ *   mean[b,:] = sum_t h[b,t,:] * mask[b,t] / max(sum_t mask[b,t], 1)
+ * h [B,T,d] f32, mask [B,T] u8 (used by value, as the reference multiplies by the mask),
+ * mean [B,d] f32, inv_count [B] f32 = 1 / max(sum mask, 1) (kept for the backward).
+ * Backward: dh[b,t,:] = mask[b,t] * g[b,:] * inv_count[b]   (dh is OVERWRITTEN).
+ * ------------------------------------------------------------------------------------- */
+int pclip_masked_mean_fwd(const float* h, const uint8_t* mask, int B, int T, int d, float* mean, float* inv_count, void* stream);
+int pclip_masked_mean_bwd(const float* g, const uint8_t* mask, const float* inv_count, int B, int T, int d, float* dh, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * FILIP token-wise similarity.
  * Replaces modules/models.py:238-239 (token normalise, no epsilon) and :292-356
  * (_filip_similarity_score): sim[i,j,a,b] = hA[i,a].hB[j,b] / t; padded pairs -> finfo.min;

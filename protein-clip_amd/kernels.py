@@ -37,6 +37,39 @@ def _scalar(t, device, name):
     return torch.tensor([float(t)], dtype=F32, device=device)
 
 
+# ---- masked mean over tokens ------------------------------------------------------------
+def _mask_bytes(mask: torch.Tensor, shape) -> torch.Tensor:
+    """[B,T] mask as one byte per token holding its VALUE (attention masks are 0/1)."""
+    if mask.dtype == torch.uint8:
+        m8 = mask.contiguous()
+    elif mask.dtype == torch.bool:
+        m8 = mask.contiguous().view(torch.uint8)
+    else:
+        m8 = mask.to(torch.uint8).contiguous()
+    if tuple(m8.shape) != tuple(shape) or not m8.is_cuda:
+        raise _lib.PclipError("masked_mean: mask must be a GPU tensor of shape [B,T]")
+    return m8
+
+
+def masked_mean_fwd(h: torch.Tensor, mask: torch.Tensor):
+    """h [B,T,d] f32, mask [B,T] -> (mean [B,d], inv_count [B], mask bytes)."""
+    require_gpu_tensor(h, F32, "h")
+    B, T, d = h.shape
+    m8 = _mask_bytes(mask, (B, T))
+    mean = torch.empty(B, d, dtype=F32, device=h.device)
+    inv = torch.empty(B, dtype=F32, device=h.device)
+    check(_lib.load().pclip_masked_mean_fwd(ptr(h), ptr(m8), B, T, d, ptr(mean), ptr(inv), stream_of(h)), "pclip_masked_mean_fwd")
+    return mean, inv, m8
+
+
+def masked_mean_bwd(g: torch.Tensor, m8: torch.Tensor, inv: torch.Tensor, T: int) -> torch.Tensor:
+    require_gpu_tensor(g, F32, "g")
+    B, d = g.shape
+    dh = torch.empty(B, T, d, dtype=F32, device=g.device)
+    check(_lib.load().pclip_masked_mean_bwd(ptr(g), ptr(m8), ptr(inv), B, T, d, ptr(dh), stream_of(g)), "pclip_masked_mean_bwd")
+    return dh
+
+
 # ---- L2 normalise + scale ---------------------------------------------------------------
 def l2norm_scale_fwd(e: torch.Tensor, t) -> torch.Tensor:
     require_gpu_tensor(e, F32, "e")

@@ -4,6 +4,7 @@ Everything up to the head output is ordinary PyTorch-ROCm (frozen ESM trunk, Lin
 LayerNorm / ReLU / Dropout).  The lines of the reference that sit on the contrastive hot path
 are replaced by HIP operators:
 
+* ``Encoder._masked_mean`` (models.py:76-90) -> :func:`protein_clip_amd.ops.masked_mean`;
 * ``Encoder.forward`` tail, ``F.normalize(e) * exp(t/2)`` (models.py:50-51)
   -> :func:`protein_clip_amd.ops.l2norm_scale`;
 * ``ExtendedFILIP.forward`` token normalisation + ``_filip_similarity_score``
@@ -56,8 +57,8 @@ class Encoder(nn.Module):
 
     @staticmethod
     def _masked_mean(h, mask):
-        weights = mask.unsqueeze(-1).to(h.dtype)
-        return (h * weights).sum(dim=1) / mask.sum(dim=1, keepdim=True).clamp(min=1).to(h.dtype)
+        """Masked mean over tokens (models.py:76-90) on the HIP kernel."""
+        return ops.masked_mean(h.float(), mask).to(h.dtype)
 
 
 class ExtendedCLIP(nn.Module):

@@ -70,6 +70,28 @@ class _L2NormScale(torch.autograd.Function):
         return de, dt.reshape(t.shape).to(t.dtype), None
 
 
+class _MaskedMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, mask, K):
+        mean, inv, m8 = K.masked_mean_fwd(h.contiguous(), mask)
+        ctx.save_for_backward(m8, inv)
+        ctx.K, ctx.T = K, h.shape[1]
+        return mean
+
+    @staticmethod
+    def backward(ctx, g):
+        m8, inv = ctx.saved_tensors
+        return ctx.K.masked_mean_bwd(g.contiguous(), m8, inv, ctx.T), None, None
+
+
+def masked_mean(h: torch.Tensor, mask: torch.Tensor, kernels=None) -> torch.Tensor:
+    """``sum_t h[b,t,:] * mask[b,t] / max(sum_t mask[b,t], 1)`` — Encoder._masked_mean of the
+    reference (modules/models.py:76-90) as one pass over ``h`` (and one in the backward)."""
+    if h.dim() != 3 or tuple(mask.shape) != tuple(h.shape[:2]):
+        raise ValueError("masked_mean: expected h [B,T,d] and mask [B,T]")
+    return _MaskedMean.apply(h, mask, kernels or _hip_kernels)
+
+
 def l2norm_scale(e: torch.Tensor, temperature: torch.Tensor, kernels=None) -> torch.Tensor:
     """``F.normalize(e, dim=-1) * torch.exp(temperature / 2)`` as one kernel each way."""
     return _L2NormScale.apply(e, temperature, kernels or _hip_kernels)

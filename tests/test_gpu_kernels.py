@@ -193,6 +193,27 @@ def test_rowce_uniform_logits_give_log_B(K):
     close(loss, torch.tensor([math.log(64.0)]), 1e-6, 1e-6)
 
 
+def test_masked_mean_matches_the_reference_formula(K):
+    """Encoder._masked_mean (modules/models.py:76-90): forward and backward against autograd of
+    the same formula, widths with and without a 16-byte row pitch, an empty sequence, int64 masks."""
+    from protein_clip_amd import ops
+    gen = torch.Generator().manual_seed(12)
+    for B, T, d in [(3, 7, 128), (5, 300, 128), (2, 33, 20), (4, 65, 130), (1, 1, 7)]:
+        h = torch.randn(B, T, d, generator=gen)
+        mask = (torch.rand(B, T, generator=gen) > 0.4).to(torch.int64)
+        if B > 1:
+            mask[1] = 0
+        href = h.clone().requires_grad_(True)
+        want = (href * mask.unsqueeze(-1)).sum(1) / mask.sum(1, keepdim=True).clamp(min=1)
+        gout = torch.randn(B, d, generator=gen)
+        want.backward(gout)
+        hd = dev(h).requires_grad_(True)
+        got = ops.masked_mean(hd, dev(mask))
+        got.backward(dev(gout))
+        close(got, want.detach(), 1e-5, 1e-6)
+        close(hd.grad, href.grad, 1e-6, 1e-7)
+
+
 # ------------------------------------------------------------------------------------------
 # FILIP
 # ------------------------------------------------------------------------------------------

@@ -68,7 +68,8 @@ def make_inputs(rank, clip_bl, filip_bl, device):
 
 def cpu_baseline(cpu, clip_b, filip_b):
     """Oracle (PyTorch-CPU restatement of the reference path) on the host cores: CLIP at the
-    full batch; FILIP on the first 32x32 block of sequence pairs, scaled by (B/32)^2."""
+    full batch; FILIP on the first 64x64 block of sequence pairs, scaled by (B/64)^2 (about
+    ten seconds of CPU work in all)."""
     from oracle import pclip_oracle as O
     t = torch.tensor(1.0)
     ts = []
@@ -77,7 +78,7 @@ def cpu_baseline(cpu, clip_b, filip_b):
         O.clip_step(cpu["e_pep"][:clip_b], cpu["e_rec"][:clip_b], t)
         ts.append(time.perf_counter() - t0)
     t_clip = statistics.median(ts[2:])
-    sb = 32
+    sb = 64
     tf = []
     for _ in range(3):
         t0 = time.perf_counter()

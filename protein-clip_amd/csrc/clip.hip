@@ -356,13 +356,11 @@ extern "C" int pclip_clip_step(const float* e_pep, const float* e_rec, const flo
     void* cws = p;
     const size_t cws_bytes = pclip_clip_workspace_bytes(B, B, d);
     float* slab = (float*)(p + cws_bytes);
-    if (int rc = pclip_l2norm_scale_fwd(e_pep, t, x, B, d, stream)) return rc;
-    if (int rc = pclip_l2norm_scale_fwd(e_rec, t, y, B, d, stream)) return rc;
+    PCLIP_REQUIRE(d <= 4096, "clip_step: d=%d out of range", d);
+    if (int rc = l2norm_scale_fwd_pair_launch(e_pep, e_rec, t, x, y, B, d, dt, stream)) return rc;   // also clears dt
     if (int rc = pclip_clip_fwd(x, y, x, y, B, B, d, 0, lse_row, lse_col, loss, nullptr, 0, cws, cws_bytes, stream)) return rc;
     int ns = 1;
     if (int rc = clip_grad_launch(x, y, x, y, lse_row, lse_col, B, B, d, 0, nullptr, slab, &ns, st)) return rc;
-    if (hipMemsetAsync(dt, 0, sizeof(float), st) != hipSuccess) return pclip_fail(PCLIP_ELAUNCH, "clip_step: memset failed");
     const size_t n = (size_t)B * d;
-    if (int rc = pclip_l2norm_scale_bwd(e_pep, t, slab, ns, n, nullptr, de_pep, dt, B, d, stream)) return rc;
-    return pclip_l2norm_scale_bwd(e_rec, t, slab + (size_t)ns * n, ns, n, nullptr, de_rec, dt, B, d, stream);
+    return l2norm_scale_bwd_pair_launch(e_pep, e_rec, t, slab, slab + (size_t)ns * n, ns, n, de_pep, de_rec, dt, B, d, stream);
 }

@@ -183,6 +183,20 @@ int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int
                         const float* gA, const float* gB,
                         float* dnA, float* dnB, float* dt, void* ws, size_t ws_bytes, void* stream);
 
+/* Steps 3 and 4 in one call, for callers that want d loss / d (raw token embeddings) and have
+ * no use for dn (no gradient exchange between the two): same inputs as pclip_filip_sim_bwd plus
+ * the raw embeddings hA [Br,TA,d], hB [Bc,TB,d] that went into pclip_filip_prep (with this
+ * `normalise`, and with `t` as the A side's tsign); outputs dhA [Br,TA,d], dhB [Bc,TB,d]
+ * (OVERWRITTEN), dt accumulated.  The window partials are summed inside the prep backward, so
+ * dn is never written.  Workspace: pclip_filip_bwd_fused_workspace_bytes. */
+size_t pclip_filip_bwd_fused_workspace_bytes(int Br, int TA, int Bc, int TB);
+int pclip_filip_bwd_fused(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
+                          const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,
+                          const float* t, const float* sim_A, const float* sim_B,
+                          const uint16_t* argA, const uint16_t* argB, const float* gA, const float* gB,
+                          const float* hA, const float* hB, int d, int normalise,
+                          float* dhA, float* dhB, float* dt, void* ws, size_t ws_bytes, void* stream);
+
 /* Step 4, backward of prep: dn [B,Tp,128] f32 (padded layout) -> dh [B,T,d] f32 through the
  * normalise Jacobian (I - n n^T)/|h| when normalise = 1 (identity otherwise), sign flipped
  * when tsign (as in prep) is negative.  When `accumulate` is nonzero dh += instead of dh =. */

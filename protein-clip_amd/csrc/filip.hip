@@ -57,9 +57,13 @@ __global__ __launch_bounds__(256) void filip_prep_kernel(const float* __restrict
 // ---- prep backward: dn [B,Tp,128] f32 -> dh [B,T,d] f32 --------------------------------
 // Masked and padding tokens carry a zero dn (the score backward never touches them), so
 // their dh comes out zero without consulting the mask.
-__global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dn, int B, int T, int d,
+__global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dn, int nslab,
+                                                             size_t slab_stride, const uint32_t* __restrict__ mw, int B, int T, int d,
                                                              int Tp, int normalise, const float* __restrict__ tsign, int accumulate,
                                                              float* __restrict__ dh) {
+    // dn is the sum of `nslab` slabs `slab_stride` floats apart (the partial gradients of the
+    // windowed backward); with mask words given, rows of padding tokens are taken as zero
+    // without being read.
     const bool negate = tsign && tsign[0] < 0.f;
     const int lane = threadIdx.x & 63;
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -69,9 +73,15 @@ __global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __rest
     const float* gr = dn + ((size_t)seq * Tp + tok) * FD;
     float* out = dh + row * d;
     const int k = 2 * lane;
+    const bool live = !mw || ((mw[(size_t)seq * (Tp >> 5) + (tok >> 5)] >> (tok & 31)) & 1u);
     float g0 = 0.f, g1 = 0.f, v0 = 0.f, v1 = 0.f;
-    if (k < d) { g0 = gr[k]; v0 = hr[k]; }
-    if (k + 1 < d) { g1 = gr[k + 1]; v1 = hr[k + 1]; }
+    if (k < d) v0 = hr[k];
+    if (k + 1 < d) v1 = hr[k + 1];
+    if (live)
+        for (int s = 0; s < nslab; ++s) {
+            if (k < d) g0 += gr[(size_t)s * slab_stride + k];
+            if (k + 1 < d) g1 += gr[(size_t)s * slab_stride + k + 1];
+        }
     const float sgn = negate ? -1.f : 1.f;
     float o0 = g0 * sgn, o1 = g1 * sgn;
     if (normalise) {
@@ -86,6 +96,16 @@ __global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __rest
     }
     if (k < d) out[k] = accumulate ? out[k] + o0 : o0;
     if (k + 1 < d) out[k + 1] = accumulate ? out[k + 1] + o1 : o1;
+}
+
+// internal: prep backward over a sum of slabs (used by the fused backward of filip_bwd.hip)
+int filip_prep_bwd_launch(const float* h, const float* dn, int nslab, size_t slab_stride, const uint32_t* mw, int B, int T, int d,
+                          int normalise, const float* tsign, int accumulate, float* dh, void* stream) {
+    const int Tp = (T + 31) / 32 * 32;
+    const size_t rows = (size_t)B * T;
+    hipLaunchKernelGGL(filip_prep_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, dn, nslab, slab_stride, mw,
+                       B, T, d, Tp, normalise, tsign, accumulate, dh);
+    return pclip_check_launch("filip_prep_bwd_kernel");
 }
 
 // ---- scores ------------------------------------------------------------------------------
@@ -285,11 +305,7 @@ extern "C" int pclip_filip_prep_bwd(const float* h, const float* dn, int B, int 
                                     float* dh, void* stream) {
     PCLIP_REQUIRE(h && dn && dh, "filip_prep_bwd: null pointer");
     if (int rc = filip_dims_ok("filip_prep_bwd", B, T, d)) return rc;
-    const int Tp = (T + 31) / 32 * 32;
-    const size_t rows = (size_t)B * T;
-    hipLaunchKernelGGL(filip_prep_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, dn, B, T, d, Tp, normalise,
-                       tsign, accumulate, dh);
-    return pclip_check_launch("filip_prep_bwd_kernel");
+    return filip_prep_bwd_launch(h, dn, 1, 0, nullptr, B, T, d, normalise, tsign, accumulate, dh, stream);
 }
 
 extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,

@@ -284,6 +284,7 @@ static BwdPlan bwd_plan(int Np, int TPp) {
 
 struct BwdWs {
     size_t listA, listB, segA, segB, icA, icB, partA, partB, total;
+    size_t dnA, dnB, total_fused;   // fused entry: scratch dn of a side that runs as a single window
     BwdPlan planA, planB;   // A-side pass (partners = B) and B-side pass (partners = A)
 };
 static BwdWs bwd_ws_layout(int Br, int TA, int Bc, int TB) {
@@ -301,6 +302,9 @@ static BwdWs bwd_ws_layout(int Br, int TA, int Bc, int TB) {
     w.partA = off; off += w.planA.nwt > 1 ? pclip_align_up((size_t)BWD_XCDS * Br * TAp * FD * 4, 256) : 0;   // partials of dnA
     w.partB = off; off += w.planB.nwt > 1 ? pclip_align_up((size_t)BWD_XCDS * Bc * TBp * FD * 4, 256) : 0;
     w.total = off;
+    w.dnA = off; off += w.planA.nwt > 1 ? 0 : pclip_align_up((size_t)Br * TAp * FD * 4, 256);
+    w.dnB = off; off += w.planB.nwt > 1 ? 0 : pclip_align_up((size_t)Bc * TBp * FD * 4, 256);
+    w.total_fused = off;
     return w;
 }
 
@@ -308,9 +312,22 @@ extern "C" size_t pclip_filip_bwd_workspace_bytes(int Br, int TA, int Bc, int TB
     if (Br < 1 || Bc < 1 || TA < 1 || TB < 1) return 0;
     return bwd_ws_layout(Br, TA, Bc, TB).total;
 }
+extern "C" size_t pclip_filip_bwd_fused_workspace_bytes(int Br, int TA, int Bc, int TB) {
+    if (Br < 1 || Bc < 1 || TA < 1 || TB < 1) return 0;
+    return bwd_ws_layout(Br, TA, Bc, TB).total_fused;
+}
 
-// gather launches of one side (eight windows each) and the sum of the partials
-static void bwd_gather_side(FilipBwdArgs a, float* part, float* dn, hipStream_t st) {
+// What follows the gathers of one side: nothing but the window sum (dn wanted), or the backward
+// of prep straight from the partials (dh wanted; dn is never formed).
+struct BwdTail {
+    const float* h;      // raw token embeddings [No,T,d], or NULL for "write dn"
+    float* dh;
+    int T, d, normalise;
+    const float* tsign;
+};
+
+// gather launches of one side (eight windows each), then the sum of the partials or the fused tail
+static int bwd_gather_side(FilipBwdArgs a, float* part, float* dn, const BwdTail& tail, hipStream_t st) {
     const int nslot = a.nwt < BWD_XCDS ? a.nwt : BWD_XCDS;
     a.dn = a.nwt > 1 ? part : dn;
     for (int w0 = 0; w0 < a.nwt; w0 += BWD_XCDS) {
@@ -318,23 +335,29 @@ static void bwd_gather_side(FilipBwdArgs a, float* part, float* dn, hipStream_t 
         a.accumulate = w0 > 0;
         hipLaunchKernelGGL(filip_gather_kernel, dim3(a.No * (a.TOp / 16) * nslot), dim3(256), 0, st, a);
     }
-    if (a.nwt > 1) {
-        const size_t n4 = (size_t)a.No * a.TOp * FD / 4;
-        hipLaunchKernelGGL(filip_window_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float4*)part, n4, nslot, (float4*)dn, a.mwO, a.TOp);
-    }
+    const size_t n = (size_t)a.No * a.TOp * FD;
+    if (tail.h)   // padding rows of the partials were never written: the mask words keep them out
+        return filip_prep_bwd_launch(tail.h, a.dn, nslot, n, a.nwt > 1 ? a.mwO : nullptr, a.No, tail.T, tail.d, tail.normalise, tail.tsign, 0,
+                                     tail.dh, st);
+    if (a.nwt > 1)
+        hipLaunchKernelGGL(filip_window_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (const float4*)part, n / 4, nslot,
+                           (float4*)dn, a.mwO, a.TOp);
+    return PCLIP_OK;
 }
 
-extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
-                                   int Bc, int TB, const float* t, const float* sim_A, const float* sim_B, const uint16_t* argA,
-                                   const uint16_t* argB, const float* gA, const float* gB, float* dnA, float* dnB, float* dt, void* ws,
-                                   size_t ws_bytes, void* stream) {
-    PCLIP_REQUIRE(hnA && maskwA && hnB && maskwB && t && sim_A && sim_B && argA && argB && gA && gB && dnA && dnB && dt && ws,
-                  "filip_sim_bwd: null pointer");
-    PCLIP_REQUIRE(Br >= 1 && Bc >= 1 && Br <= 65535 && Bc <= 65535, "filip_sim_bwd: Br=%d Bc=%d (need 1..65535)", Br, Bc);
-    PCLIP_REQUIRE(TA >= 1 && TA <= PCLIP_FILIP_MAX_T_LONG && TB >= 1 && TB <= PCLIP_FILIP_MAX_T_LONG, "filip_sim_bwd: TA=%d TB=%d (need 1..%d)",
+static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
+                         int TB, const float* t, const float* sim_A, const float* sim_B, const uint16_t* argA, const uint16_t* argB,
+                         const float* gA, const float* gB, float* dnA, float* dnB, const BwdTail& tailA, const BwdTail& tailB, float* dt,
+                         void* ws, size_t ws_bytes, void* stream) {
+    PCLIP_REQUIRE(hnA && maskwA && hnB && maskwB && t && sim_A && sim_B && argA && argB && gA && gB && dt && ws, "filip backward: null pointer");
+    PCLIP_REQUIRE(Br >= 1 && Bc >= 1 && Br <= 65535 && Bc <= 65535, "filip backward: Br=%d Bc=%d (need 1..65535)", Br, Bc);
+    PCLIP_REQUIRE(TA >= 1 && TA <= PCLIP_FILIP_MAX_T_LONG && TB >= 1 && TB <= PCLIP_FILIP_MAX_T_LONG, "filip backward: TA=%d TB=%d (need 1..%d)",
                   TA, TB, PCLIP_FILIP_MAX_T_LONG);
     const BwdWs L = bwd_ws_layout(Br, TA, Bc, TB);
-    PCLIP_REQUIRE(ws_bytes >= L.total, "filip_sim_bwd: workspace %zu < %zu bytes", ws_bytes, L.total);
+    const size_t need = (tailA.h || tailB.h) ? L.total_fused : L.total;
+    PCLIP_REQUIRE(ws_bytes >= need, "filip backward: workspace %zu < %zu bytes", ws_bytes, need);
+    if (tailA.h) dnA = (float*)((char*)ws + L.dnA);   // scratch, used only when the side runs as one window
+    if (tailB.h) dnB = (float*)((char*)ws + L.dnB);
     const int TAp = tp32(TA), TBp = tp32(TB);
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
@@ -366,11 +389,33 @@ extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, 
             }
         }
         hipLaunchKernelGGL(filip_invert_kernel, dim3((unsigned)((size_t)u.No * u.nwt)), dim3(INV_THREADS), lds, st, u, stage);
-        bwd_gather_side(u, (float*)(w + (side == 0 ? L.partA : L.partB)), side == 0 ? dnA : dnB, st);
+        if (int rc = bwd_gather_side(u, (float*)(w + (side == 0 ? L.partA : L.partB)), side == 0 ? dnA : dnB, side == 0 ? tailA : tailB, st))
+            return rc;
         if (int rc = pclip_check_launch(side == 0 ? "filip backward (A side)" : "filip backward (B side)")) return rc;
     }
     const size_t n = (size_t)Br * Bc;
     const int blocks = (int)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
     hipLaunchKernelGGL(filip_dt_kernel, dim3(blocks), dim3(256), 0, st, gA, gB, sim_A, sim_B, n, t, dt);
     return pclip_check_launch("filip_dt_kernel");
+}
+
+extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
+                                   int Bc, int TB, const float* t, const float* sim_A, const float* sim_B, const uint16_t* argA,
+                                   const uint16_t* argB, const float* gA, const float* gB, float* dnA, float* dnB, float* dt, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    PCLIP_REQUIRE(dnA && dnB, "filip_sim_bwd: null pointer");
+    const BwdTail none = {nullptr, nullptr, 0, 0, 0, nullptr};
+    return filip_bwd_impl(hnA, maskwA, Br, TA, hnB, maskwB, Bc, TB, t, sim_A, sim_B, argA, argB, gA, gB, dnA, dnB, none, none, dt, ws, ws_bytes,
+                          stream);
+}
+
+extern "C" int pclip_filip_bwd_fused(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
+                                     int Bc, int TB, const float* t, const float* sim_A, const float* sim_B, const uint16_t* argA,
+                                     const uint16_t* argB, const float* gA, const float* gB, const float* hA, const float* hB, int d,
+                                     int normalise, float* dhA, float* dhB, float* dt, void* ws, size_t ws_bytes, void* stream) {
+    PCLIP_REQUIRE(hA && hB && dhA && dhB, "filip_bwd_fused: null pointer");
+    PCLIP_REQUIRE(d >= 1 && d <= PCLIP_FILIP_MAX_D, "filip_bwd_fused: d=%d (need 1 <= d <= %d)", d, PCLIP_FILIP_MAX_D);
+    const BwdTail tA = {hA, dhA, TA, d, normalise, t}, tB = {hB, dhB, TB, d, normalise, nullptr};
+    return filip_bwd_impl(hnA, maskwA, Br, TA, hnB, maskwB, Bc, TB, t, sim_A, sim_B, argA, argB, gA, gB, nullptr, nullptr, tA, tB, dt, ws,
+                          ws_bytes, stream);
 }

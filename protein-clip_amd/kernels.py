@@ -257,6 +257,27 @@ def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB,
     return dnA, dnB, dt
 
 
+def filip_bwd_fused(hnA, mwA, hnB, mwB, t, simA, simB, argA, argB, gA, gB, hA, hB, normalise: bool,
+                    dt: Optional[torch.Tensor] = None):
+    """Score backward and prep backward in one call (single-GPU path: no gradient exchange between
+    the two).  hA [Br,TA,d], hB [Bc,TB,d]: the raw embeddings given to ``filip_prep`` (A side with
+    ``tsign=t``).  Returns (dhA, dhB, dt)."""
+    dev = hnA.device
+    for n, v in (("gA", gA), ("gB", gB), ("hA", hA), ("hB", hB)):
+        require_gpu_tensor(v, F32, n)
+    (Br, TA, d), (Bc, TB, _) = hA.shape, hB.shape
+    tt = _scalar(t, dev, "t")
+    dhA, dhB = torch.empty_like(hA), torch.empty_like(hB)
+    if dt is None:
+        dt = torch.zeros(1, dtype=F32, device=dev)
+    lib = _lib.load()
+    ws = _workspace(dev, lib.pclip_filip_bwd_fused_workspace_bytes(Br, TA, Bc, TB))
+    check(lib.pclip_filip_bwd_fused(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), ptr(simA), ptr(simB), ptr(argA),
+                                    ptr(argB), ptr(gA), ptr(gB), ptr(hA), ptr(hB), d, int(normalise), ptr(dhA), ptr(dhB), ptr(dt), ptr(ws),
+                                    ws.numel(), stream_of(hnA)), "pclip_filip_bwd_fused")
+    return dhA, dhB, dt
+
+
 def filip_prep_bwd(h, dn, normalise: bool, tsign=None, out: Optional[torch.Tensor] = None):
     require_gpu_tensor(h, F32, "h")
     require_gpu_tensor(dn, F32, "dn")
@@ -272,7 +293,7 @@ def filip_prep_bwd(h, dn, normalise: bool, tsign=None, out: Optional[torch.Tenso
 class FilipStep:
     """Pre-allocated FILIP hot-path step for one shape: raw token embeddings -> normalise ->
     scores -> both row InfoNCE losses -> every gradient.  ``run`` only enqueues kernels on the
-    current stream (12 C calls); ``sim_events`` optionally brackets the score kernel with the
+    current stream (10 C calls); ``sim_events`` optionally brackets the score kernel with the
     two given ``torch.cuda.Event``s so its duration can be read after a sync."""
 
     def __init__(self, Br: int, Bc: int, TA: int, TB: int, d: int, device, row_offset: int = 0, Bg=None):
@@ -287,10 +308,9 @@ class FilipStep:
         self.argA, self.argB = e(Br, Bc, TAp, dt=torch.int16), e(Br, Bc, TBp, dt=torch.int16)
         self.lseA, self.lseB, self.lossA, self.lossB = e(Br), e(Br), e(1), e(1)
         self.gA, self.gB = e(Br, Bc), e(Br, Bc)
-        self.dnA, self.dnB = e(Br, TAp, 128), e(Bc, TBp, 128)
         self.dhA, self.dhB = e(Br, TA, d), e(Bc, TB, d)
         self.dt = e(1)
-        self.bws = e(_lib.load().pclip_filip_bwd_workspace_bytes(Br, TA, Bc, TB), dt=torch.uint8)
+        self.bws = e(_lib.load().pclip_filip_bwd_fused_workspace_bytes(Br, TA, Bc, TB), dt=torch.uint8)
 
     def run(self, hA, hB, mA8, mB8, t, sim_events=None):
         """hA [Br,TA,d], hB [Bc,TB,d] f32; mA8/mB8 uint8 masks; t 1-element f32 tensor (all on
@@ -312,9 +332,8 @@ class FilipStep:
         check(lib.pclip_rowce_bwd(ptr(self.simA), ptr(self.lseA), Br, Bc, off, Bg, 0, None, 0.5, ptr(self.gA), st), "pclip_rowce_bwd")
         check(lib.pclip_rowce_bwd(ptr(self.simB), ptr(self.lseB), Br, Bc, off, Bg, 0, None, 0.5, ptr(self.gB), st), "pclip_rowce_bwd")
         self.dt.zero_()
-        check(lib.pclip_filip_sim_bwd(ptr(self.hnA), ptr(self.mwA), Br, TA, ptr(self.hnB), ptr(self.mwB), Bc, TB, ptr(t), ptr(self.simA),
-                                      ptr(self.simB), ptr(self.argA), ptr(self.argB), ptr(self.gA), ptr(self.gB), ptr(self.dnA),
-                                      ptr(self.dnB), ptr(self.dt), ptr(self.bws), self.bws.numel(), st), "pclip_filip_sim_bwd")
-        check(lib.pclip_filip_prep_bwd(ptr(hA), ptr(self.dnA), Br, TA, d, 1, ptr(t), 0, ptr(self.dhA), st), "pclip_filip_prep_bwd")
-        check(lib.pclip_filip_prep_bwd(ptr(hB), ptr(self.dnB), Bc, TB, d, 1, None, 0, ptr(self.dhB), st), "pclip_filip_prep_bwd")
+        check(lib.pclip_filip_bwd_fused(ptr(self.hnA), ptr(self.mwA), Br, TA, ptr(self.hnB), ptr(self.mwB), Bc, TB, ptr(t), ptr(self.simA),
+                                        ptr(self.simB), ptr(self.argA), ptr(self.argB), ptr(self.gA), ptr(self.gB), ptr(hA), ptr(hB), d, 1,
+                                        ptr(self.dhA), ptr(self.dhB), ptr(self.dt), ptr(self.bws), self.bws.numel(), st),
+              "pclip_filip_bwd_fused")
         return self.lossA, self.lossB, self.dhA, self.dhB, self.dt

@@ -208,18 +208,19 @@ class _FilipSim(torch.autograd.Function):
         hA, hB, hnA, mwA, hnB_all, mwB_all, t, simA, simB, argA, argB = ctx.saved_tensors
         normalise, TA, TB, group, world, rank = ctx.cfg
         K = ctx.K
-        dnA, dnB_all, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA.contiguous(),
-                                          gB.contiguous())
         if _collective(world):
+            dnA, dnB_all, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA.contiguous(),
+                                              gB.contiguous())
             # every rank holds a partial gradient for every B sequence: sum and hand each rank its own
             dnB = torch.empty((hB.shape[0],) + tuple(dnB_all.shape[1:]), dtype=dnB_all.dtype, device=dnB_all.device)
             dist.reduce_scatter_tensor(dnB, dnB_all, group=group)
             # dt stays this rank's share, like every shared-parameter gradient: the trainer's
             # gradient all-reduce (SUM) completes it
-        else:
-            dnB = dnB_all
-        dhA = K.filip_prep_bwd(hA, dnA, normalise, tsign=t)
-        dhB = K.filip_prep_bwd(hB, dnB, normalise)
+            dhA = K.filip_prep_bwd(hA, dnA, normalise, tsign=t)
+            dhB = K.filip_prep_bwd(hB, dnB, normalise)
+        else:   # no exchange between the score backward and the prep backward: one fused call
+            dhA, dhB, dt = K.filip_bwd_fused(hnA, mwA, hnB_all, mwB_all, t, simA, simB, argA, argB, gA.contiguous(), gB.contiguous(), hA,
+                                             hB, normalise)
         return dhA, dhB, None, None, dt.reshape(t.shape).to(t.dtype), None, None, None
 
 

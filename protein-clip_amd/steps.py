@@ -116,14 +116,14 @@ class FilipShardedStep:
         lseB, lossB = K.rowce_fwd(simB, off, Bg, False)
         gA = K.rowce_bwd(simA, lseA, off, Bg, False, gscale=0.5)
         gB = K.rowce_bwd(simB, lseB, off, Bg, False, gscale=0.5)
-        dnA, dnB_all, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB)
         if _collective(W):
+            dnA, dnB_all, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB)
             dnB = torch.empty((Bl,) + tuple(dnB_all.shape[1:]), dtype=dnB_all.dtype, device=dnB_all.device)
             dist.reduce_scatter_tensor(dnB, dnB_all, group=self.group)
-        else:
-            dnB = dnB_all
-        dhA = K.filip_prep_bwd(hA, dnA, True, tsign=t)
-        dhB = K.filip_prep_bwd(hB, dnB, True)
+            dhA = K.filip_prep_bwd(hA, dnA, True, tsign=t)
+            dhB = K.filip_prep_bwd(hB, dnB, True)
+        else:   # one GPU: no exchange between the two backward stages, so they run fused
+            dhA, dhB, dt = K.filip_bwd_fused(hnA, mwA, hnB_all, mwB_all, t, simA, simB, argA, argB, gA, gB, hA, hB, True)
         pack = torch.cat([lossA.reshape(1), lossB.reshape(1), dt.reshape(1)])
         if _collective(W):
             dist.all_reduce(pack, group=self.group)

@@ -144,3 +144,8 @@ def filip_prep_bwd(h, dn, normalise, tsign=None, out=None):
         out += res
         return out
     return res
+
+
+def filip_bwd_fused(hnA, mwA, hnB, mwB, t, simA, simB, argA, argB, gA, gB, hA, hB, normalise, dt=None):
+    dnA, dnB, out_dt = filip_sim_bwd(hnA, mwA, hA.shape[1], hnB, mwB, hB.shape[1], t, simA, simB, argA, argB, gA, gB, dt)
+    return filip_prep_bwd(hA, dnA, normalise, tsign=t), filip_prep_bwd(hB, dnB, normalise), out_dt

@@ -500,3 +500,33 @@ def test_filip_random_small_shapes_against_oracle(K):
             raise AssertionError(f"{tag}: {exc}") from None
         if bool(ok.all()):
             assert torch.allclose(dt.cpu(), dt_ref.reshape(1), rtol=1e-4, atol=1e-5), tag
+
+
+@pytest.mark.parametrize("window_kb", [None, "16"])
+def test_filip_fused_backward_equals_the_two_calls(K, monkeypatch, window_kb):
+    """pclip_filip_bwd_fused (score backward + prep backward, partials summed inside the latter)
+    against pclip_filip_sim_bwd followed by pclip_filip_prep_bwd, single window and windowed."""
+    if window_kb is None:
+        monkeypatch.delenv("PCLIP_FILIP_BWD_WINDOW_KB", raising=False)
+    else:
+        monkeypatch.setenv("PCLIP_FILIP_BWD_WINDOW_KB", window_kb)
+    gen = torch.Generator().manual_seed(31)
+    for normalise, d, tval in [(True, 128, 0.9), (False, 20, -1.1)]:
+        Br, Bc, TA, TB = 11, 13, 37, 70
+        hA, hB = torch.randn(Br, TA, d, generator=gen), torch.randn(Bc, TB, d, generator=gen)
+        mA = (torch.rand(Br, TA, generator=gen) > 0.3).to(torch.uint8)
+        mB = (torch.rand(Bc, TB, generator=gen) > 0.3).to(torch.uint8)
+        mA[:, 0] = 1
+        mB[:, 0] = 1
+        t = dev(torch.tensor([tval]))
+        gA, gB = dev(torch.randn(Br, Bc, generator=gen)), dev(torch.randn(Br, Bc, generator=gen))
+        hAd, hBd = dev(hA), dev(hB)
+        hnA, mwA = K.filip_prep(hAd, dev(mA), normalise, tsign=t)
+        hnB, mwB = K.filip_prep(hBd, dev(mB), normalise)
+        simA, simB, argA, argB = K.filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, unit_norm=normalise)
+        dnA, dnB, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB)
+        want = (K.filip_prep_bwd(hAd, dnA, normalise, tsign=t), K.filip_prep_bwd(hBd, dnB, normalise), dt)
+        got = K.filip_bwd_fused(hnA, mwA, hnB, mwB, t, simA, simB, argA, argB, gA, gB, hAd, hBd, normalise)
+        for a, b in zip(got, want):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+    monkeypatch.delenv("PCLIP_FILIP_BWD_WINDOW_KB", raising=False)

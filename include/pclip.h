@@ -174,7 +174,9 @@ int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int
  * or PCLIP_FILIP_BWD_WINDOW_KB from the environment, which must not change between the
  * workspace query and the call).  The order in
  * which a row's contributions are summed is not fixed, so results may differ in the last
- * bits from run to run. */
+ * bits from run to run.  Either of dnA, dnB may be NULL: that side is skipped (dt is produced
+ * together with dnA), so a caller can run the B side first and start exchanging dnB between
+ * GPUs while the A side is computed. */
 size_t pclip_filip_bwd_workspace_bytes(int Br, int TA, int Bc, int TB);
 int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
                         const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,

@@ -376,6 +376,7 @@ static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
     b.icO = icB; b.icP = icA; b.seg = (int*)(w + L.segB); b.list = (uint32_t*)(w + L.listB); b.dn = nullptr;
     b.nwt = L.planB.nwt; b.qpw = L.planB.qpw; b.win0 = 0; b.accumulate = 0;
     for (int side = 0; side < 2; ++side) {
+        if (!(side == 0 ? dnA : dnB)) continue;   // pclip_filip_sim_bwd: that side was not asked for
         const FilipBwdArgs& u = side == 0 ? a : b;
         const size_t cap = (size_t)u.qpw * u.TPp;                       // entries of one window at most
         const int stage = cap <= INV_STAGE_MAX ? (int)cap : 0;
@@ -395,6 +396,7 @@ static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
     }
     const size_t n = (size_t)Br * Bc;
     const int blocks = (int)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
+    if (!dnA) return PCLIP_OK;   // dt goes with the A side
     hipLaunchKernelGGL(filip_dt_kernel, dim3(blocks), dim3(256), 0, st, gA, gB, sim_A, sim_B, n, t, dt);
     return pclip_check_launch("filip_dt_kernel");
 }
@@ -403,7 +405,7 @@ extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, 
                                    int Bc, int TB, const float* t, const float* sim_A, const float* sim_B, const uint16_t* argA,
                                    const uint16_t* argB, const float* gA, const float* gB, float* dnA, float* dnB, float* dt, void* ws,
                                    size_t ws_bytes, void* stream) {
-    PCLIP_REQUIRE(dnA && dnB, "filip_sim_bwd: null pointer");
+    PCLIP_REQUIRE(dnA || dnB, "filip_sim_bwd: null pointer (dnA and dnB)");
     const BwdTail none = {nullptr, nullptr, 0, 0, 0, nullptr};
     return filip_bwd_impl(hnA, maskwA, Br, TA, hnB, maskwB, Bc, TB, t, sim_A, sim_B, argA, argB, gA, gB, dnA, dnB, none, none, dt, ws, ws_bytes,
                           stream);

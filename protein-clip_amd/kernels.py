@@ -239,14 +239,16 @@ def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True
     return simA, simB, argA, argB
 
 
-def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt: Optional[torch.Tensor] = None):
+def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt: Optional[torch.Tensor] = None, sides: str = "AB"):
+    """Returns (dnA, dnB, dt).  ``sides``: "AB" (both), "A" (dnA and dt; dnB is None) or "B" (dnB only;
+    dnA and dt are None) — the multi-GPU step runs "B" first and reduce-scatters dnB while "A" runs."""
     dev = hnA.device
     Br, Bc = hnA.shape[0], hnB.shape[0]
     tt = _scalar(t, dev, "t")
     require_gpu_tensor(gA, F32, "gA")
     require_gpu_tensor(gB, F32, "gB")
-    dnA = torch.empty(Br, _tp(TA), 128, dtype=F32, device=dev)
-    dnB = torch.empty(Bc, _tp(TB), 128, dtype=F32, device=dev)
+    dnA = torch.empty(Br, _tp(TA), 128, dtype=F32, device=dev) if "A" in sides else None
+    dnB = torch.empty(Bc, _tp(TB), 128, dtype=F32, device=dev) if "B" in sides else None
     if dt is None:
         dt = torch.zeros(1, dtype=F32, device=dev)
     lib = _lib.load()
@@ -254,7 +256,7 @@ def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB,
     check(lib.pclip_filip_sim_bwd(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), ptr(simA), ptr(simB),
                                   ptr(argA), ptr(argB), ptr(gA), ptr(gB), ptr(dnA), ptr(dnB), ptr(dt), ptr(ws), ws.numel(),
                                   stream_of(hnA)), "pclip_filip_sim_bwd")
-    return dnA, dnB, dt
+    return dnA, dnB, (dt if "A" in sides else None)
 
 
 def filip_bwd_fused(hnA, mwA, hnB, mwB, t, simA, simB, argA, argB, gA, gB, hA, hB, normalise: bool,

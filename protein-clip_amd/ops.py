@@ -209,14 +209,17 @@ class _FilipSim(torch.autograd.Function):
         normalise, TA, TB, group, world, rank = ctx.cfg
         K = ctx.K
         if _collective(world):
-            dnA, dnB_all, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA.contiguous(),
-                                              gB.contiguous())
-            # every rank holds a partial gradient for every B sequence: sum and hand each rank its own
+            gA, gB = gA.contiguous(), gB.contiguous()
+            # every rank holds a partial gradient for every B sequence: the B side runs first, and
+            # its reduce-scatter (sum, each rank gets its own sequences) beside the A side's kernels
+            _, dnB_all, _ = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB, sides="B")
             dnB = torch.empty((hB.shape[0],) + tuple(dnB_all.shape[1:]), dtype=dnB_all.dtype, device=dnB_all.device)
-            dist.reduce_scatter_tensor(dnB, dnB_all, group=group)
+            work = dist.reduce_scatter_tensor(dnB, dnB_all, group=group, async_op=True)
             # dt stays this rank's share, like every shared-parameter gradient: the trainer's
             # gradient all-reduce (SUM) completes it
+            dnA, _, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB, sides="A")
             dhA = K.filip_prep_bwd(hA, dnA, normalise, tsign=t)
+            work.wait()
             dhB = K.filip_prep_bwd(hB, dnB, normalise)
         else:   # no exchange between the score backward and the prep backward: one fused call
             dhA, dhB, dt = K.filip_bwd_fused(hnA, mwA, hnB_all, mwB_all, t, simA, simB, argA, argB, gA.contiguous(), gB.contiguous(), hA,

@@ -117,10 +117,14 @@ class FilipShardedStep:
         gA = K.rowce_bwd(simA, lseA, off, Bg, False, gscale=0.5)
         gB = K.rowce_bwd(simB, lseB, off, Bg, False, gscale=0.5)
         if _collective(W):
-            dnA, dnB_all, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB)
+            # B side first: its gradient is the one that travels (every rank holds a share for every
+            # B sequence), and the reduce-scatter then runs beside the A side's kernels
+            _, dnB_all, _ = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB, sides="B")
             dnB = torch.empty((Bl,) + tuple(dnB_all.shape[1:]), dtype=dnB_all.dtype, device=dnB_all.device)
-            dist.reduce_scatter_tensor(dnB, dnB_all, group=self.group)
+            work = dist.reduce_scatter_tensor(dnB, dnB_all, group=self.group, async_op=True)
+            dnA, _, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB, sides="A")
             dhA = K.filip_prep_bwd(hA, dnA, True, tsign=t)
+            work.wait()
             dhB = K.filip_prep_bwd(hB, dnB, True)
         else:   # one GPU: no exchange between the two backward stages, so they run fused
             dhA, dhB, dt = K.filip_bwd_fused(hnA, mwA, hnB_all, mwB_all, t, simA, simB, argA, argB, gA, gB, hA, hB, True)

@@ -118,17 +118,19 @@ def filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, want_arg=True, unit_norm=False)
     return simA, simB, aA.to(torch.int16), aB.to(torch.int16)
 
 
-def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt=None):
+def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt=None, sides="AB"):
     a = hnA.detach().clone().requires_grad_(True)
     b = hnB.detach().clone().requires_grad_(True)
     with torch.enable_grad():
         sA, sB, _, _ = _scores(a, mwA, b, mwB, t)
         ((sA * gA).sum() + (sB * gB).sum()).backward()
-    out_dt = (-(gA * simA + gB * simB).sum() / _s(t)).reshape(1)
-    if dt is not None:
-        dt += out_dt
-        out_dt = dt
-    return a.grad, b.grad, out_dt
+    out_dt = None
+    if "A" in sides:
+        out_dt = (-(gA * simA + gB * simB).sum() / _s(t)).reshape(1)
+        if dt is not None:
+            dt += out_dt
+            out_dt = dt
+    return (a.grad if "A" in sides else None), (b.grad if "B" in sides else None), out_dt
 
 
 def filip_prep_bwd(h, dn, normalise, tsign=None, out=None):

@@ -77,11 +77,22 @@ __global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __rest
     float g0 = 0.f, g1 = 0.f, v0 = 0.f, v1 = 0.f;
     if (k < d) v0 = hr[k];
     if (k + 1 < d) v1 = hr[k + 1];
-    if (live)
-        for (int s = 0; s < nslab; ++s) {
-            if (k < d) g0 += gr[(size_t)s * slab_stride + k];
-            if (k + 1 < d) g1 += gr[(size_t)s * slab_stride + k + 1];
+    if (live) {   // dn rows are 128 floats wide whatever d is: one 8-byte load per slab, eight in flight
+        int s = 0;
+        for (; s + 8 <= nslab; s += 8) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(gr + (size_t)(s + u) * slab_stride + k);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { g0 += v[u].x; g1 += v[u].y; }
         }
+        for (; s < nslab; ++s) {
+            const float2 v = *reinterpret_cast<const float2*>(gr + (size_t)s * slab_stride + k);
+            g0 += v.x; g1 += v.y;
+        }
+        if (k >= d) g0 = 0.f;
+        if (k + 1 >= d) g1 = 0.f;
+    }
     const float sgn = negate ? -1.f : 1.f;
     float o0 = g0 * sgn, o1 = g1 * sgn;
     if (normalise) {

@@ -31,7 +31,8 @@ struct FilipBwdArgs {
     const uint16_t* arg2;  // [pair][TPp]  own token chosen by each partner token
     const float* g1;       // [pair] d loss / d score averaged over OWN tokens
     const float* g2;       // [pair] d loss / d score averaged over PARTNER tokens
-    size_t so, sp;         // pair index = own*so + partner*sp
+    size_t so, sp;         // pair index into arg1 / arg2 = own*so + partner*sp
+    size_t gso, gsp;       // pair index into g1 / g2 = own*gso + partner*gsp (partner-contiguous copies)
     const float* t;
     const float* icO;      // [No] 1/max(valid own tokens, 1e-6), 0 where the sequence is empty
     const float* icP;      // [Np] same for partners
@@ -57,6 +58,29 @@ __global__ __launch_bounds__(256) void filip_count_kernel(const uint32_t* __rest
     int c = 0;
     for (int k = 0; k < nt; ++k) c += __popc(mw[(size_t)s * nt + k]);
     ic[s] = c > 0 ? 1.f / (float)c : 0.f;
+}
+
+// [R][C] -> [C][R] for the two upstream-gradient matrices at once (tiny: the B-side pass reads
+// them partner-contiguous, as the A-side pass reads the originals)
+__global__ __launch_bounds__(256) void filip_transpose2_kernel(const float* __restrict__ a, const float* __restrict__ b, int R, int C,
+                                                               float* __restrict__ aT, float* __restrict__ bT) {
+    __shared__ float tile[2][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        const bool in = r < R && c < C;
+        tile[0][k][tx] = in ? a[(size_t)r * C + c] : 0.f;
+        tile[1][k][tx] = in ? b[(size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (r < R && c < C) {
+            aT[(size_t)c * R + r] = tile[0][tx][k];
+            bT[(size_t)c * R + r] = tile[1][tx][k];
+        }
+    }
 }
 
 // One workgroup per (own sequence, partner window): counting sort of the window's valid partner
@@ -177,7 +201,7 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
             if (q < q_hi) {
                 const size_t pair = (size_t)o * p.so + (size_t)q * p.sp;
                 b = p.arg1[pair * p.TOp + a];
-                w = p.icP[q] > 0.f ? p.g1[pair] * c1 : 0.f;
+                w = p.icP[q] > 0.f ? p.g1[(size_t)o * p.gso + (size_t)q * p.gsp] * c1 : 0.f;
             }
             bf16x8 rows[16];
             float ws[16];
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
             if (pos < end) {
                 ent = list[pos];
                 const int q = ent >> 16;
-                w = p.g2[(size_t)o * p.so + (size_t)q * p.sp] * p.icP[q] * inv_t;
+                w = p.g2[(size_t)o * p.gso + (size_t)q * p.gsp] * p.icP[q] * inv_t;
             }
             bf16x8 rows[16];
             float ws[16];
@@ -283,7 +307,7 @@ static BwdPlan bwd_plan(int Np, int TPp) {
 }
 
 struct BwdWs {
-    size_t listA, listB, segA, segB, icA, icB, partA, partB, total;
+    size_t listA, listB, segA, segB, icA, icB, gT, partA, partB, total;
     size_t dnA, dnB, total_fused;   // fused entry: scratch dn of a side that runs as a single window
     BwdPlan planA, planB;   // A-side pass (partners = B) and B-side pass (partners = A)
 };
@@ -299,6 +323,7 @@ static BwdWs bwd_ws_layout(int Br, int TA, int Bc, int TB) {
     w.segB = off;  off += pclip_align_up((size_t)Bc * w.planB.nwt * (TBp + 1) * 4, 256);
     w.icA = off;   off += pclip_align_up((size_t)Br * 4, 256);
     w.icB = off;   off += pclip_align_up((size_t)Bc * 4, 256);
+    w.gT = off;    off += pclip_align_up((size_t)2 * Br * Bc * 4, 256);   // transposed copies of gA, gB
     w.partA = off; off += w.planA.nwt > 1 ? pclip_align_up((size_t)BWD_XCDS * Br * TAp * FD * 4, 256) : 0;   // partials of dnA
     w.partB = off; off += w.planB.nwt > 1 ? pclip_align_up((size_t)BWD_XCDS * Bc * TBp * FD * 4, 256) : 0;
     w.total = off;
@@ -364,15 +389,19 @@ static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
     float* icA = (float*)(w + L.icA);
     float* icB = (float*)(w + L.icB);
     hipLaunchKernelGGL(filip_count_kernel, dim3((Br + Bc + 255) / 256), dim3(256), 0, st, maskwA, Br, TAp / 32, icA, maskwB, Bc, TBp / 32, icB);
+    float* gAT = (float*)(w + L.gT);
+    float* gBT = gAT + (size_t)Br * Bc;
+    if (dnB)
+        hipLaunchKernelGGL(filip_transpose2_kernel, dim3((Bc + 31) / 32, (Br + 31) / 32), dim3(256), 0, st, gA, gB, Br, Bc, gAT, gBT);
     FilipBwdArgs a, b;
     // gradient of the A images: own = A(i), partner = B(j), pair = i*Bc + j
     a.hnP = hnB; a.mwO = maskwA; a.mwP = maskwB; a.No = Br; a.TOp = TAp; a.Np = Bc; a.TPp = TBp;
-    a.arg1 = argA; a.arg2 = argB; a.g1 = gA; a.g2 = gB; a.so = (size_t)Bc; a.sp = 1; a.t = t;
+    a.arg1 = argA; a.arg2 = argB; a.g1 = gA; a.g2 = gB; a.so = (size_t)Bc; a.sp = 1; a.gso = (size_t)Bc; a.gsp = 1; a.t = t;
     a.icO = icA; a.icP = icB; a.seg = (int*)(w + L.segA); a.list = (uint32_t*)(w + L.listA); a.dn = nullptr;
     a.nwt = L.planA.nwt; a.qpw = L.planA.qpw; a.win0 = 0; a.accumulate = 0;
     // gradient of the B images: own = B(j), partner = A(i), pair = i*Bc + j
     b.hnP = hnA; b.mwO = maskwB; b.mwP = maskwA; b.No = Bc; b.TOp = TBp; b.Np = Br; b.TPp = TAp;
-    b.arg1 = argB; b.arg2 = argA; b.g1 = gB; b.g2 = gA; b.so = 1; b.sp = (size_t)Bc; b.t = t;
+    b.arg1 = argB; b.arg2 = argA; b.g1 = gBT; b.g2 = gAT; b.so = 1; b.sp = (size_t)Bc; b.gso = (size_t)Br; b.gsp = 1; b.t = t;
     b.icO = icB; b.icP = icA; b.seg = (int*)(w + L.segB); b.list = (uint32_t*)(w + L.listB); b.dn = nullptr;
     b.nwt = L.planB.nwt; b.qpw = L.planB.qpw; b.win0 = 0; b.accumulate = 0;
     for (int side = 0; side < 2; ++side) {

@@ -128,9 +128,9 @@ class FilipShardedStep:
             dhB = K.filip_prep_bwd(hB, dnB, True)
         else:   # one GPU: no exchange between the two backward stages, so they run fused
             dhA, dhB, dt = K.filip_bwd_fused(hnA, mwA, hnB_all, mwB_all, t, simA, simB, argA, argB, gA, gB, hA, hB, True)
-        pack = torch.cat([lossA.reshape(1), lossB.reshape(1), dt.reshape(1)])
-        if _collective(W):
-            dist.all_reduce(pack, group=self.group)
-        loss = (pack[0:1] + pack[1:2]) * 0.5
         self.last = {"simA": simA, "simB": simB}
-        return loss, dhA, dhB, pack[2:3]
+        if _collective(W):
+            pack = torch.cat([lossA.reshape(1), lossB.reshape(1), dt.reshape(1)])
+            dist.all_reduce(pack, group=self.group)
+            return (pack[0:1] + pack[1:2]) * 0.5, dhA, dhB, pack[2:3]
+        return torch.add(lossA.reshape(1), lossB.reshape(1), alpha=1.0).mul_(0.5), dhA, dhB, dt.reshape(1)

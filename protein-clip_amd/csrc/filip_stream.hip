@@ -31,6 +31,9 @@ unsigned long long* g_stream_dbg = nullptr;
 #else
 #define STAMP(k) do {} while (0)
 #endif
+#ifndef STREAM_WGS
+#define STREAM_WGS 1024      // workgroups aimed at per launch (about four per CU); 768..2048 measured alike
+#endif
 #ifndef ABL_MFMA_STEPS
 #define ABL_MFMA_STEPS 8   // timing experiments only: fewer k-steps (wrong results)
 #endif
@@ -389,9 +392,6 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     for (int e = 0; e < nE; ++e) {
         const bool ahead = e + SNE - 1 < nE;
         if (ahead) issue_epoch(e + SNE - 1);
-#ifdef ABL_STAGGER
-        if (w >= 8) __builtin_amdgcn_s_sleep(ABL_STAGGER);
-#endif
         STAMP(0);
         const int ring0 = (e % SNE) * SE;
         const int par2 = e & 1, par3 = e % 3;
@@ -419,9 +419,6 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                     for (int s = 0; s < 8; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(base + 1024 * s);
                 }
                 const f32x16 two = {2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f};
-#ifdef ABL_PRIO
-                __builtin_amdgcn_s_setprio(ABL_PRIO);
-#endif
                 f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], two, 0, 0, 0);
 #pragma unroll
                 for (int s = 1; s < ABL_MFMA_STEPS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], bfr[s], acc, 0, 0, 0);
@@ -435,9 +432,6 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#endif
-#ifdef ABL_PRIO
-                __builtin_amdgcn_s_setprio(0);
 #endif
 #ifdef STREAM_STAMPS
                 asm volatile("s_nop 0" ::"v"(acc));   // the matrix results have arrived
@@ -556,9 +550,6 @@ int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br,
     a.ngroups = (Br + 1) / 2;
 #ifdef STREAM_STAMPS
     a.dbg = g_stream_dbg;
-#endif
-    #ifndef STREAM_WGS
-#define STREAM_WGS 1024
 #endif
     int nchunk = (STREAM_WGS + a.ngroups - 1) / a.ngroups;   // about four workgroups per CU over the launch
     int jchunk = (Bc + nchunk - 1) / nchunk;

@@ -70,6 +70,13 @@ class _L2NormScale(torch.autograd.Function):
         return de, dt.reshape(t.shape).to(t.dtype), None
 
 
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    """Half / bfloat16 activations (a caller running under autocast, as the reference's ``train_gc``
+    does) are upcast here, through autograd; the kernels compute in f32 (bf16 MFMA operands for
+    FILIP) whatever the caller's precision context is."""
+    return t if t.dtype == torch.float32 or not t.is_floating_point() else t.float()
+
+
 class _MaskedMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, mask, K):
@@ -89,12 +96,12 @@ def masked_mean(h: torch.Tensor, mask: torch.Tensor, kernels=None) -> torch.Tens
     reference (modules/models.py:76-90) as one pass over ``h`` (and one in the backward)."""
     if h.dim() != 3 or tuple(mask.shape) != tuple(h.shape[:2]):
         raise ValueError("masked_mean: expected h [B,T,d] and mask [B,T]")
-    return _MaskedMean.apply(h, mask, kernels or _hip_kernels)
+    return _MaskedMean.apply(_f32(h), mask, kernels or _hip_kernels)
 
 
 def l2norm_scale(e: torch.Tensor, temperature: torch.Tensor, kernels=None) -> torch.Tensor:
     """``F.normalize(e, dim=-1) * torch.exp(temperature / 2)`` as one kernel each way."""
-    return _L2NormScale.apply(e, temperature, kernels or _hip_kernels)
+    return _L2NormScale.apply(_f32(e), _f32(temperature), kernels or _hip_kernels)
 
 
 # --------------------------------------------------------------------------------------
@@ -139,14 +146,14 @@ def clip_loss(x: torch.Tensor, y: torch.Tensor, group=None, kernels=None) -> tor
     backward yields gradients for the rank's own rows."""
     if x.dim() != 2 or x.shape != y.shape:
         raise ValueError(f"clip_loss: expected two [B,d] tensors of one shape, got {tuple(x.shape)} and {tuple(y.shape)}")
-    return _ClipLoss.apply(x, y, group, kernels or _hip_kernels)
+    return _ClipLoss.apply(_f32(x), _f32(y), group, kernels or _hip_kernels)
 
 
 def clip_exp_logits(x: torch.Tensor, y: torch.Tensor, kernels=None) -> torch.Tensor:
     """``exp(x @ y.T)`` — what ``get_logits`` returns (modules/training_utils.py:170-172)."""
     K = kernels or _hip_kernels
-    x = x.detach().contiguous()
-    y = y.detach().contiguous()
+    x = _f32(x.detach()).contiguous()
+    y = _f32(y.detach()).contiguous()
     return K.clip_fwd(x, y, x, y, 0, logits_mode=2)[3]
 
 
@@ -179,7 +186,7 @@ def row_ce(logits: torch.Tensor, use_dcl: bool = False, row_offset: int = 0, glo
     if logits.dim() != 2:
         raise ValueError("row_ce: expected a 2-d logits tensor")
     Bg = logits.shape[0] if global_batch is None else global_batch
-    return _RowCE.apply(logits, bool(use_dcl), row_offset, Bg, group, kernels or _hip_kernels)
+    return _RowCE.apply(_f32(logits), bool(use_dcl), row_offset, Bg, group, kernels or _hip_kernels)
 
 
 # --------------------------------------------------------------------------------------
@@ -238,5 +245,5 @@ def filip_similarity(hA, hB, maskA, maskB, temperature, normalise: bool = False,
     if tuple(maskA.shape) != tuple(hA.shape[:2]) or tuple(maskB.shape) != tuple(hB.shape[:2]):
         raise ValueError("filip_similarity: masks must be [B,T] matching the embeddings")
     t = temperature if isinstance(temperature, torch.Tensor) else torch.tensor(float(temperature), device=hA.device)
-    simA, simB, _, _ = _FilipSim.apply(hA, hB, maskA, maskB, t, bool(normalise), group, kernels or _hip_kernels)
+    simA, simB, _, _ = _FilipSim.apply(_f32(hA), _f32(hB), maskA, maskB, _f32(t), bool(normalise), group, kernels or _hip_kernels)
     return simA, simB

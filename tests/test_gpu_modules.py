@@ -171,3 +171,25 @@ def test_entry_scripts_run_offline(env, script, extra, monkeypatch, tmp_path):
     kind = "clip" if script == "main" else "filip"
     head_keys = {k for k in env["trace"][kind]["state_dict_keys"] if "esm_model" not in k}
     assert head_keys and head_keys <= keys
+
+
+def test_operators_accept_half_precision_activations(env):
+    """A caller under autocast (the reference's train_gc decorates its loss with @autocast) hands
+    the operators fp16 / bf16 activations: they are upcast through autograd and the gradients come
+    back in the caller's dtype."""
+    from protein_clip_amd import ops
+    g = torch.Generator().manual_seed(3)
+    t = torch.tensor(1.0, device="cuda", requires_grad=True)
+    for dt in (torch.float16, torch.bfloat16):
+        e1 = torch.randn(16, 128, generator=g).cuda().to(dt).requires_grad_(True)
+        e2 = torch.randn(16, 128, generator=g).cuda().to(dt).requires_grad_(True)
+        loss = ops.clip_loss(ops.l2norm_scale(e1, t), ops.l2norm_scale(e2, t))
+        hA = torch.randn(4, 20, 128, generator=g).cuda().to(dt).requires_grad_(True)
+        hB = torch.randn(4, 24, 128, generator=g).cuda().to(dt).requires_grad_(True)
+        mA, mB = torch.ones(4, 20, device="cuda"), torch.ones(4, 24, device="cuda")
+        sA, sB = ops.filip_similarity(hA, hB, mA, mB, t, normalise=True)
+        total = loss + (ops.row_ce(sA) + ops.row_ce(sB)) / 2 + ops.masked_mean(hA, mA).sum()
+        total.backward()
+        assert total.dtype == torch.float32 and torch.isfinite(total)
+        for x in (e1, e2, hA, hB):
+            assert x.grad is not None and x.grad.dtype == dt and torch.isfinite(x.grad.float()).all()

@@ -116,10 +116,19 @@ __device__ __forceinline__ float half32_sum(float v) {
 //   APART: some rows of the A tile are padding -> their keys are kept out of the column maximum
 //          through the lane masks rm[r] (bit l = row of register r is valid in lane l); what
 //          they add to the row keys of padding rows is never read.
-template <bool APART>
-__device__ __forceinline__ int tile_keys(const f32x16& acc, int (&KM)[16], int rmask, int rtag, const unsigned long long (&rm)[16]) {
+// Row side.  FRESH: the first product of a B sequence overwrites the running maxima, which saves
+// both the sixteen maxima here and a reset of the sixteen registers after every sequence.
+template <bool FRESH>
+__device__ __forceinline__ void row_keys(const f32x16& acc, int (&KM)[16], int rmask, int rtag) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) KM[r] = max(KM[r], and_or_i(__float_as_int(acc[r]), rmask, rtag));
+    for (int r = 0; r < 16; ++r) {
+        const int k = and_or_i(__float_as_int(acc[r]), rmask, rtag);
+        KM[r] = FRESH ? k : max(KM[r], k);
+    }
+}
+
+template <bool APART>
+__device__ __forceinline__ int col_keys(const f32x16& acc, const unsigned long long (&rm)[16]) {
     int cb = NEG_KEY;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
@@ -340,6 +349,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     int KM[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) KM[r] = NEG_KEY;
+    bool fresh = true;   // wave-uniform: no product of the current B sequence has been folded into KM yet
 
     // prologue: epochs 0 .. SNE-2 in flight, epoch 0 landed
     for (int E = 0; E < SNE - 1; ++E)
@@ -411,6 +421,14 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         for (int q = 0; q < SE; ++q) {
             const uint32_t wB = t_wB[q], mz = t_mz[q], fl = t_fl[q];
             const int bt = (mz >> 8) & 7;
+            // Issue priority by progress: of the four waves on a SIMD the one that is furthest behind
+            // in the epoch goes first.  Left alone the SIMD serves its oldest wave first, the waves
+            // finish the epoch one after the other and the last one runs its products alone, at a
+            // third of the issue rate, while the others wait at the barrier (5 % of the kernel).
+            if (q == 0) __builtin_amdgcn_s_setprio(3);
+            else if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
             if (wB != 0 && wA != 0) {
                 bf16x8 bfr[8];
                 {
@@ -442,7 +460,10 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
 #else
                 const bool colok = (wB >> c) & 1u;
                 const int rmask = colok ? ~7 : 0, rtag = colok ? bt : NEG_KEY;
-                const int cb = apart ? tile_keys<true>(acc, KM, rmask, rtag, rm) : tile_keys<false>(acc, KM, rmask, rtag, rm);
+                if (fresh) row_keys<true>(acc, KM, rmask, rtag);
+                else row_keys<false>(acc, KM, rmask, rtag);
+                fresh = false;
+                const int cb = apart ? col_keys<true>(acc, rm) : col_keys<false>(acc, rm);
                 atomicMax(&col64[((par2 * SE + q) * 2 + slot_isel) * 32 + c], ((long long)cb << 32) | (long long)((slot_at << 1) | h));
 #endif
                 STAMP(3);
@@ -451,10 +472,9 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 // ---- rows of the finished B sequence: transpose the keys, lane (row, half) scans 16 ----
                 int* tr = reinterpret_cast<int*>(smem + C::S_TR) + w * 32 * 36;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    tr[acc_row(r, h) * 36 + c] = KM[r];
-                    KM[r] = NEG_KEY;
-                }
+                for (int r = 0; r < 16; ++r) tr[acc_row(r, h) * 36 + c] = KM[r];
+                const bool empty_b = fresh;   // an empty B sequence: nothing was folded in, KM is stale
+                fresh = true;
                 __builtin_amdgcn_wave_barrier();
                 int k16[16];
                 {
@@ -469,13 +489,17 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 const int a0 = max3_i(k16[0], k16[1], k16[2]), a1 = max3_i(k16[3], k16[4], k16[5]), a2 = max3_i(k16[6], k16[7], k16[8]);
                 const int a3 = max3_i(k16[9], k16[10], k16[11]), a4 = max3_i(k16[12], k16[13], k16[14]);
                 int m = max(max3_i(a0, a1, a2), max3_i(a3, a4, k16[15]));
+                m = empty_b ? NEG_KEY : m;
                 int cc = 15;
 #pragma unroll
                 for (int k = 14; k >= 0; --k) cc = (k16[k] == m) ? k : cc;
                 cc += 16 * h;
                 {
+                    // the lower half holds the lower columns: it wins ties
                     const int om = __shfl_xor(m, 32), oc = __shfl_xor(cc, 32);
-                    if (om > m || (om == m && oc < cc)) { m = om; cc = oc; }
+                    const bool take = om + h > m;
+                    m = take ? om : m;
+                    cc = take ? oc : cc;
                 }
                 // every lane of both halves now holds row `c` of the tile: key m, winning lane cc
                 const bool valid = (wA >> c) & 1u;
@@ -496,6 +520,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS atomics and writes are done
         STAMP(5);
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(3);   // duty waves start the next epoch behind the others
         STAMP(6);
 
         // ---- columns of this epoch's tiles, by SE waves: waves without an A tile when there are

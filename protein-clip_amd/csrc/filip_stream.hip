@@ -524,8 +524,9 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         STAMP(6);
 
         // ---- columns of this epoch's tiles, by SE waves: waves without an A tile when there are
-        // enough of them, else a different set every epoch ----------------------------------------
-        const int duty0 = (NW - n_items >= SE) ? NW - SE : (e % (NW / SE)) * SE;
+        // enough of them, else the oldest one of every SIMD (served first, they have the most slack
+        // before the next barrier: 1 % faster than rotating the duty) ------------------------------
+        const int duty0 = (NW - n_items >= SE) ? NW - SE : 0;
         if (w >= duty0 && w < duty0 + SE) {
             const int q = w - duty0, isel = h;
             const uint4 m4 = meta[e * SE + q];

@@ -394,6 +394,44 @@ def test_filip_benchmark_size_matches_reference_scores(K):
     assert torch.allclose(sub[4], simA[:16, 32:48], atol=1e-6) and torch.allclose(sub[5], simB[:16, 32:48], atol=1e-6)
 
 
+def test_filip_benchmark_size_backward_rows_against_oracle(K):
+    """B = 256, L = 256, d = 128 (eight partner windows in the backward): the gradients of two
+    whole A sequences and two whole B sequences against the oracle's autograd of exactly the
+    pairs they take part in, plus two size-independent properties over every token: the gradient
+    of a normalised token is orthogonal to it, and padding tokens get none.  A token's gradient
+    row here sums about 500 routed contributions; one arg-max near-tie among them (keys drop the
+    low 3-4 mantissa bits) moves the whole 128-wide row by a few percent, so a few percent of the
+    elements sit outside the elementwise tolerance while the relative L2 error stays small."""
+    gen = torch.Generator().manual_seed(5)
+    B, L, d = 256, 256, 128
+    hA = O.bf16_round(torch.randn(B, L, d, generator=gen))
+    hB = O.bf16_round(torch.randn(B, L, d, generator=gen))
+    mA = O.right_padded_masks(torch.randint(100, L + 1, (B,), generator=gen), L)
+    mB = O.right_padded_masks(torch.randint(100, L + 1, (B,), generator=gen), L)
+    tt = torch.tensor(0.07)
+    gA, gB = torch.randn(B, B, generator=gen) / B, torch.randn(B, B, generator=gen) / B
+    t = dev(tt.reshape(1))
+    hnA, mwA = K.filip_prep(dev(hA), dev(mA), True, tsign=t)
+    hnB, mwB = K.filip_prep(dev(hB), dev(mB), True)
+    simA, simB, argA, argB = K.filip_sim_fwd(hnA, mwA, L, hnB, mwB, L, t, unit_norm=True)
+    dnA, dnB, dt = K.filip_sim_bwd(hnA, mwA, L, hnB, mwB, L, t, simA, simB, argA, argB, dev(gA), dev(gB))
+    dA = K.filip_prep_bwd(dev(hA), dnA, normalise=True, tsign=t).cpu()
+    dB = K.filip_prep_bwd(dev(hB), dnB, normalise=True).cpu()
+    for i in (3, 200):   # A sequence i against every B sequence
+        sA, sB, da, _, _ = _oracle_filip_grads(hA[i:i + 1], hB, mA[i:i + 1], mB, tt, True, gA[i:i + 1], gB[i:i + 1])
+        close(simA[i:i + 1], sA, 3e-5, 3e-5)   # 1/t = 14 scales the 2e-6 of the unit-temperature scores
+        close(simB[i:i + 1], sB, 3e-5, 3e-5)
+        mostly_close(dA[i:i + 1], da, 1e-3, 1e-7, max_bad_frac=0.06, max_rel_l2=0.02)
+    for j in (0, 131):   # every A sequence against B sequence j
+        _, _, _, db, _ = _oracle_filip_grads(hA, hB[j:j + 1], mA, mB[j:j + 1], tt, True, gA[:, j:j + 1], gB[:, j:j + 1])
+        mostly_close(dB[j:j + 1], db, 1e-3, 1e-7, max_bad_frac=0.06, max_rel_l2=0.02)
+    for h, dh, m in ((hA, dA, mA), (hB, dB, mB)):
+        assert (dh[~m.bool()] == 0).all()
+        dots = (dh * h).sum(-1)[m.bool()]
+        scale = (dh.norm(dim=-1) * h.norm(dim=-1))[m.bool()]
+        assert (dots.abs() <= 1e-4 * scale + 1e-9).all()
+
+
 def test_filip_rank_shape_decomposes_over_partner_blocks(K):
     """One rank of a 3-GPU job: 64 A sequences against 3 x 256 gathered B sequences, L = 256
     (the backward then needs three gather launches of eight 2-MB windows each).  The two

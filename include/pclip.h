@@ -155,7 +155,9 @@ int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, i
  * (argA/argB feed the backward, which reads the entries of valid tokens only; entries of
  * padding tokens are unspecified and may be left unwritten.  Pass NULL for both to skip them
  * in inference.)  Setting the environment variable PCLIP_FILIP_KERNEL=old before the call
- * selects the earlier non-streaming unit-norm kernel (kept for A/B timing).
+ * selects the earlier non-streaming unit-norm kernel (kept for A/B timing);
+ * PCLIP_FILIP_STREAM_WGS=<n> (read once) overrides the number of workgroups the streaming
+ * kernel aims at per launch (default 512).
  * TA, TB <= PCLIP_FILIP_MAX_T_LONG; sequences beyond PCLIP_FILIP_MAX_T tokens (the reference keeps
  * chains of up to 2,000 residues, modules/data_utils_2protein.py:88) run on a general, untuned
  * kernel. */

@@ -22,6 +22,7 @@
 // Rows finish once per (A tile, B sequence) by transposing the 32x32 keys through a per-wave
 // LDS pad; columns finish once per epoch, after its barrier, by a rotating subset of waves.
 #include "pclip_common.h"
+#include <stdlib.h>
 
 // Diagnostic build (-DSTREAM_STAMPS): every wave adds up the shader-clock cycles it spends in
 // eight segments of the main loop and stores them to g_stream_dbg[(block*16 + wave)*8 + k].
@@ -32,7 +33,8 @@ unsigned long long* g_stream_dbg = nullptr;
 #define STAMP(k) do {} while (0)
 #endif
 #ifndef STREAM_WGS
-#define STREAM_WGS 1024      // workgroups aimed at per launch (about four per CU); 768..2048 measured alike
+#define STREAM_WGS 512       // workgroups aimed at per launch (two per CU): a workgroup's set-up costs about 6 us and
+                             // nothing overlaps it (one workgroup fills a CU's LDS); 1024 is 2 % slower, 2048 4 %
 #endif
 #ifndef ABL_MFMA_STEPS
 #define ABL_MFMA_STEPS 8   // timing experiments only: fewer k-steps (wrong results)
@@ -577,7 +579,13 @@ int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br,
 #ifdef STREAM_STAMPS
     a.dbg = g_stream_dbg;
 #endif
-    int nchunk = (STREAM_WGS + a.ngroups - 1) / a.ngroups;   // about four workgroups per CU over the launch
+    static int wgs_target = 0;   // PCLIP_FILIP_STREAM_WGS overrides the default (tuning and tests)
+    if (wgs_target == 0) {
+        const char* e = getenv("PCLIP_FILIP_STREAM_WGS");
+        const int v = e ? atoi(e) : 0;
+        wgs_target = v >= 1 && v <= 65536 ? v : STREAM_WGS;
+    }
+    int nchunk = (wgs_target + a.ngroups - 1) / a.ngroups;   // about two workgroups per CU over the launch
     int jchunk = (Bc + nchunk - 1) / nchunk;
     if (jchunk < 8) jchunk = Bc < 8 ? Bc : 8;
     if (jchunk > SMAXJ) jchunk = SMAXJ;

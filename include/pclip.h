@@ -116,6 +116,16 @@ int pclip_rowce_fwd(const float* logits, int Br, int Bc, int row_offset, int Bg,
 int pclip_rowce_bwd(const float* logits, const float* lse, int Br, int Bc, int row_offset, int Bg,
                     int use_dcl, const float* g, float gscale, float* dlogits, void* stream);
 
+/* Both FILIP losses with their gradients in two launches.  Replaces
+ * modules/training_utils_filip.py:26-39 (_compute_loss = (rowCE(sim_A) + rowCE(sim_B)) / 2) and
+ * the backward of that expression; equal to two pclip_rowce_fwd plus two pclip_rowce_bwd
+ * (use_dcl = 0, gscale = 0.5) followed by the average.
+ *   sim_A, sim_B [Br,Bc] f32;  lse2 [2,Br] out;  g_A, g_B [Br,Bc] out: d loss / d sim
+ *   loss3 [3] out: {(lossA + lossB) / 2, lossA, lossB}, each the share of these Br rows (1/Bg) sum
+ *   ws_terms: 2*Br floats of scratch */
+int pclip_filip_loss(const float* sim_A, const float* sim_B, int Br, int Bc, int row_offset, int Bg,
+                     float* lse2, float* loss3, float* g_A, float* g_B, float* ws_terms, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Masked mean over tokens.  Replaces Encoder._masked_mean (modules/models.py:76-90), the
  * pooling in front of the embedding head of each CLIP tower (models.py:48):

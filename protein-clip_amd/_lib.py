@@ -30,6 +30,7 @@ _SIGNATURES = {
     "pclip_clip_step": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "pclip_rowce_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "pclip_rowce_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P]),
+    "pclip_filip_loss": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "pclip_masked_mean_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "pclip_masked_mean_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "pclip_filip_prep": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),

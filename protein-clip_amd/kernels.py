@@ -197,6 +197,23 @@ def rowce_bwd(logits, lse, row_offset: int = 0, Bg: Optional[int] = None, use_dc
     return out
 
 
+def filip_loss(simA, simB, row_offset: int = 0, Bg: Optional[int] = None):
+    """Both row InfoNCE losses of the FILIP scores and their gradients (training_utils_filip.py:26-39).
+    Returns (loss3, gA, gB): loss3 = [(lossA + lossB) / 2, lossA, lossB] for these rows' share."""
+    require_gpu_tensor(simA, F32, "simA")
+    require_gpu_tensor(simB, F32, "simB")
+    Br, Bc = simA.shape
+    Bg = Br if Bg is None else Bg
+    dev = simA.device
+    lse2 = torch.empty(2, Br, dtype=F32, device=dev)
+    terms = torch.empty(2, Br, dtype=F32, device=dev)
+    loss3 = torch.empty(3, dtype=F32, device=dev)
+    gA, gB = torch.empty_like(simA), torch.empty_like(simB)
+    check(_lib.load().pclip_filip_loss(ptr(simA), ptr(simB), Br, Bc, row_offset, Bg, ptr(lse2), ptr(loss3), ptr(gA), ptr(gB), ptr(terms),
+                                       stream_of(simA)), "pclip_filip_loss")
+    return loss3, gA, gB
+
+
 # ---- FILIP ------------------------------------------------------------------------------
 def _tp(T: int) -> int:
     return (T + 31) // 32 * 32
@@ -308,7 +325,7 @@ class FilipStep:
         self.hnB, self.mwB = e(Bc, TBp, 128, dt=torch.int16), e(Bc, TBp // 32, dt=torch.int32)
         self.simA, self.simB = e(Br, Bc), e(Br, Bc)
         self.argA, self.argB = e(Br, Bc, TAp, dt=torch.int16), e(Br, Bc, TBp, dt=torch.int16)
-        self.lseA, self.lseB, self.lossA, self.lossB = e(Br), e(Br), e(1), e(1)
+        self.lse2, self.terms, self.loss3 = e(2, Br), e(2, Br), e(3)
         self.gA, self.gB = e(Br, Bc), e(Br, Bc)
         self.dhA, self.dhB = e(Br, TA, d), e(Bc, TB, d)
         self.dt = e(1)
@@ -329,13 +346,11 @@ class FilipStep:
                                       ptr(self.simB), ptr(self.argA), ptr(self.argB), st), "pclip_filip_sim_fwd")
         if sim_events is not None:
             sim_events[1].record()
-        check(lib.pclip_rowce_fwd(ptr(self.simA), Br, Bc, off, Bg, 0, ptr(self.lseA), ptr(self.lossA), st), "pclip_rowce_fwd")
-        check(lib.pclip_rowce_fwd(ptr(self.simB), Br, Bc, off, Bg, 0, ptr(self.lseB), ptr(self.lossB), st), "pclip_rowce_fwd")
-        check(lib.pclip_rowce_bwd(ptr(self.simA), ptr(self.lseA), Br, Bc, off, Bg, 0, None, 0.5, ptr(self.gA), st), "pclip_rowce_bwd")
-        check(lib.pclip_rowce_bwd(ptr(self.simB), ptr(self.lseB), Br, Bc, off, Bg, 0, None, 0.5, ptr(self.gB), st), "pclip_rowce_bwd")
+        check(lib.pclip_filip_loss(ptr(self.simA), ptr(self.simB), Br, Bc, off, Bg, ptr(self.lse2), ptr(self.loss3), ptr(self.gA), ptr(self.gB),
+                                   ptr(self.terms), st), "pclip_filip_loss")
         self.dt.zero_()
         check(lib.pclip_filip_bwd_fused(ptr(self.hnA), ptr(self.mwA), Br, TA, ptr(self.hnB), ptr(self.mwB), Bc, TB, ptr(t), ptr(self.simA),
                                         ptr(self.simB), ptr(self.argA), ptr(self.argB), ptr(self.gA), ptr(self.gB), ptr(hA), ptr(hB), d, 1,
                                         ptr(self.dhA), ptr(self.dhB), ptr(self.dt), ptr(self.bws), self.bws.numel(), st),
               "pclip_filip_bwd_fused")
-        return self.lossA, self.lossB, self.dhA, self.dhB, self.dt
+        return self.loss3[1:2], self.loss3[2:3], self.dhA, self.dhB, self.dt

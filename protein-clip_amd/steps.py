@@ -112,10 +112,7 @@ class FilipShardedStep:
         if sim_events is not None:
             sim_events[1].record()
         off = self.rank * Bl
-        lseA, lossA = K.rowce_fwd(simA, off, Bg, False)
-        lseB, lossB = K.rowce_fwd(simB, off, Bg, False)
-        gA = K.rowce_bwd(simA, lseA, off, Bg, False, gscale=0.5)
-        gB = K.rowce_bwd(simB, lseB, off, Bg, False, gscale=0.5)
+        loss3, gA, gB = K.filip_loss(simA, simB, off, Bg)   # [(lossA + lossB) / 2, lossA, lossB], d loss / d sim
         if _collective(W):
             # B side first: its gradient is the one that travels (every rank holds a share for every
             # B sequence), and the reduce-scatter then runs beside the A side's kernels
@@ -130,7 +127,7 @@ class FilipShardedStep:
             dhA, dhB, dt = K.filip_bwd_fused(hnA, mwA, hnB_all, mwB_all, t, simA, simB, argA, argB, gA, gB, hA, hB, True)
         self.last = {"simA": simA, "simB": simB}
         if _collective(W):
-            pack = torch.cat([lossA.reshape(1), lossB.reshape(1), dt.reshape(1)])
+            pack = torch.cat([loss3[0:1], dt.reshape(1)])
             dist.all_reduce(pack, group=self.group)
-            return (pack[0:1] + pack[1:2]) * 0.5, dhA, dhB, pack[2:3]
-        return torch.add(lossA.reshape(1), lossB.reshape(1), alpha=1.0).mul_(0.5), dhA, dhB, dt.reshape(1)
+            return pack[0:1], dhA, dhB, pack[1:2]
+        return loss3[0:1], dhA, dhB, dt.reshape(1)

@@ -86,6 +86,15 @@ def rowce_bwd(logits, lse, row_offset=0, Bg=None, use_dcl=False, g=None, gscale=
     return p * (gscale / Bg) * (1.0 if g is None else _s(g))
 
 
+def filip_loss(simA, simB, row_offset=0, Bg=None):
+    _, la = rowce_fwd(simA, row_offset, Bg)
+    _, lb = rowce_fwd(simB, row_offset, Bg)
+    lseA, lseB = torch.logsumexp(simA, 1), torch.logsumexp(simB, 1)
+    gA = rowce_bwd(simA, lseA, row_offset, Bg, gscale=0.5)
+    gB = rowce_bwd(simB, lseB, row_offset, Bg, gscale=0.5)
+    return torch.cat([(la + lb) * 0.5, la, lb]), gA, gB
+
+
 def _bf16(x):
     return x.to(torch.bfloat16).to(F32)
 

@@ -193,6 +193,31 @@ def test_rowce_uniform_logits_give_log_B(K):
     close(loss, torch.tensor([math.log(64.0)]), 1e-6, 1e-6)
 
 
+@pytest.mark.parametrize("Br,Bc,off", [(5, 5, 0), (64, 256, 128), (256, 256, 0), (33, 2048, 1000)])
+def test_filip_loss_equals_the_row_ce_calls_and_the_oracle(K, Br, Bc, off):
+    """The two-launch FILIP loss against the four row-CE calls it replaces and against the
+    oracle's _compute_loss on the square cases."""
+    gen = torch.Generator().manual_seed(Br * 7 + Bc)
+    sA, sB = torch.randn(Br, Bc, generator=gen) * 3, torch.randn(Br, Bc, generator=gen) * 3
+    dA, dB = dev(sA), dev(sB)
+    loss3, gA, gB = K.filip_loss(dA, dB, off, Bc)
+    lseA, lossA = K.rowce_fwd(dA, off, Bc, False)
+    lseB, lossB = K.rowce_fwd(dB, off, Bc, False)
+    close(gA, K.rowce_bwd(dA, lseA, off, Bc, False, gscale=0.5).cpu(), 1e-5, 1e-9)
+    close(gB, K.rowce_bwd(dB, lseB, off, Bc, False, gscale=0.5).cpu(), 1e-5, 1e-9)
+    close(loss3[1:2], lossA.cpu(), 1e-6, 1e-7)
+    close(loss3[2:3], lossB.cpu(), 1e-6, 1e-7)
+    close(loss3[0:1], ((lossA + lossB) / 2).cpu(), 1e-6, 1e-7)
+    if Br == Bc and off == 0:
+        a = sA.clone().requires_grad_(True)
+        b = sB.clone().requires_grad_(True)
+        ref = O.filip_loss(a, b)
+        ref.backward()
+        close(loss3[0:1], ref.detach().reshape(1), 1e-5, 1e-6)
+        close(gA, a.grad, 1e-5, 1e-8)
+        close(gB, b.grad, 1e-5, 1e-8)
+
+
 def test_masked_mean_matches_the_reference_formula(K):
     """Encoder._masked_mean (modules/models.py:76-90): forward and backward against autograd of
     the same formula, widths with and without a 16-byte row pitch, an empty sequence, int64 masks."""

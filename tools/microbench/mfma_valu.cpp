@@ -28,7 +28,7 @@ __global__ __launch_bounds__(1024) void k(const bf16x8* __restrict__ in, int* __
 #pragma unroll
         for (int v = 0; v < NV / 2; ++v) {
             const int r = v & 15;
-            km[r] = max(km[r], (__float_as_int(prev[r]) & ~7) | (it & 7) | (v >> 4));
+            km[r] = max(km[r], (__float_as_int(MODE == 2 ? acc[r] : prev[r]) & ~7) | (it & 7) | (v >> 4));
         }
         if (MODE == 1) {
 #pragma unroll
@@ -87,6 +87,16 @@ int main() {
     run<64, 1, 8>("8 MFMA x 8 VALU interleaved", in, out, cyc);
     run<64, 1, 6>("8 MFMA x 6 VALU + 16 tail", in, out, cyc);
     run<96, 0, 0>("8 MFMA then 96 VALU", in, out, cyc);
+    run<48, 2, 0>("8 MFMA, 48 VALU on ITS result", in, out, cyc);
+    run<56, 2, 0>("8 MFMA, 56 VALU on ITS result", in, out, cyc);
+    run<72, 2, 0>("8 MFMA, 72 VALU on ITS result", in, out, cyc);
+    run<80, 2, 0>("8 MFMA, 80 VALU on ITS result", in, out, cyc);
+    run<88, 2, 0>("8 MFMA, 88 VALU on ITS result", in, out, cyc);
+    run<112, 2, 0>("8 MFMA, 112 VALU on ITS result", in, out, cyc);
+    run<128, 2, 0>("8 MFMA, 128 VALU on ITS result", in, out, cyc);
+    run<32, 2, 0>("8 MFMA, 32 VALU on ITS result", in, out, cyc);
+    run<64, 2, 0>("8 MFMA, 64 VALU on ITS result", in, out, cyc);
+    run<96, 2, 0>("8 MFMA, 96 VALU on ITS result", in, out, cyc);
     run<96, 1, 12>("8 MFMA x 12 VALU interleaved", in, out, cyc);
     return 0;
 }

@@ -11,13 +11,16 @@
 // B fragments from ONE address register with immediate offsets, conflict-free.  One workgroup
 // barrier per epoch of SE tiles is the only synchronisation of the main loop.
 //
-// Per 32x32 tile: 8 v_mfma_f32_32x32x16_bf16 with the accumulator started at 2.0 (|a.b| <= 1,
-// so every valid similarity is a positive float in [1,3] whose bit pattern orders like its
-// value; padded pairs start at -FLT_MAX and stay negative).  The running row maximum and the
-// column maximum are then integer maxima of keys that carry the arg index in their low
-// mantissa bits (3 bits of B tile on the row side, 4 bits of accumulator register on the column
-// side); the dropped bits are replaced by their midpoint, so a score is within 2e-6 of the
-// exact maximum.  Column maxima of the A tiles held by different waves meet in LDS through a
+// Per 32x32 tile: 8 v_mfma_f32_32x32x16_bf16 with the accumulator started at 4.0: |a.b| <= 1,
+// so every similarity becomes a float in [3,5], whose sign and upper seven exponent bits are
+// the same for all of them.  Shifted left by seven the bit pattern still orders like the value
+// (the lowest exponent bit and all 23 mantissa bits stay) and the low seven bits are free for
+// the arg index: 3 bits of B tile for the row maxima, 4 bits of accumulator register for the
+// column maxima, ONE key per element for both sides (one v_lshl_or_b32).  Row and column
+// maxima are integer maxima of these keys; nothing of the value is dropped, a score differs
+// from the exact maximum only by the f32 rounding of the accumulation near 4 (<= 1e-6).
+// Padding columns and rows get a negative key.  Column maxima of the A tiles held by different waves
+// meet in LDS through a
 // 64-bit integer atomic max (key in the high word, A tile and lane half in the low word).
 // Rows finish once per (A tile, B sequence) by transposing the 32x32 keys through a per-wave
 // LDS pad; columns finish once per epoch, after its barrier, by a rotating subset of waves.
@@ -109,32 +112,44 @@ __device__ __forceinline__ float half32_sum(float v) {
     return v + __shfl_xor(v, 16);
 }
 
-// One finished accumulator tile -> running row keys (elementwise) and one column key per lane.
-// The column maximum is one dependent chain of max3 (two keys at a time), which needs two
-// temporaries instead of sixteen: the kernel runs at 128 registers per lane.
-//   rmask / rtag: per-lane operands of the row-key update.  A lane whose column of the B tile is
-//          valid passes (~7, B tile index); a padding column passes (0, NEG_KEY), which turns its
-//          keys into NEG_KEY and leaves the running maxima alone (its column result is never read).
-//   APART: some rows of the A tile are padding -> their keys are kept out of the column maximum
-//          through the lane masks rm[r] (bit l = row of register r is valid in lane l); what
-//          they add to the row keys of padding rows is never read.
+// One finished accumulator tile -> its 16 keys per lane, in place of the accumulator:
+// key = bits(4 + a.b) << 7 | B tile << 4 | register.  When the B tile has padding columns,
+// mask_keys gives the lanes on them (bit l of colmask clear) NEG_KEY, which leaves the running
+// row maxima alone (their column result is never read).
+#define KEY_SHIFT 7
+#define KEY_TOP 0x40000000   // the seven bits the shift drops: sign 0, exponent 100 0000x
+__device__ __forceinline__ float key_value(int key) { return __int_as_float((key >> KEY_SHIFT) | KEY_TOP) - 4.0f; }
+
+__device__ __forceinline__ void make_keys(const f32x16& acc, int (&key)[16], int bt4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int tag;   // a scalar register per tag, so that shift and tag are ONE v_lshl_or_b32
+        asm("s_or_b32 %0, %1, %2" : "=s"(tag) : "s"(bt4), "n"(r) : "scc");
+        key[r] = (int)(((uint32_t)__float_as_int(acc[r]) << KEY_SHIFT) | (uint32_t)tag);
+    }
+}
+__device__ __forceinline__ void mask_keys(int (&key)[16], unsigned long long colmask) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) key[r] = __builtin_amdgcn_inverse_ballot_w64(colmask) ? key[r] : NEG_KEY;
+}
+
 // Row side.  FRESH: the first product of a B sequence overwrites the running maxima, which saves
 // both the sixteen maxima here and a reset of the sixteen registers after every sequence.
 template <bool FRESH>
-__device__ __forceinline__ void row_keys(const f32x16& acc, int (&KM)[16], int rmask, int rtag) {
+__device__ __forceinline__ void row_fold(const int (&key)[16], int (&KM)[16]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k = and_or_i(__float_as_int(acc[r]), rmask, rtag);
-        KM[r] = FRESH ? k : max(KM[r], k);
-    }
+    for (int r = 0; r < 16; ++r) KM[r] = FRESH ? key[r] : max(KM[r], key[r]);
 }
 
+// Column side: one dependent chain of max3.  APART: some rows of the A tile are padding; their
+// keys are kept out through the lane masks rm[r] (bit l = row of register r is valid in lane l;
+// what they add to the row maxima of padding rows is never read).
 template <bool APART>
-__device__ __forceinline__ int col_keys(const f32x16& acc, const unsigned long long (&rm)[16]) {
+__device__ __forceinline__ int col_max(const int (&key)[16], const unsigned long long (&rm)[16]) {
     int cb = NEG_KEY;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        int k0 = and_or_i(__float_as_int(acc[r]), ~15, r), k1 = and_or_i(__float_as_int(acc[r + 1]), ~15, r + 1);
+        int k0 = key[r], k1 = key[r + 1];
         if (APART) {
             k0 = __builtin_amdgcn_inverse_ballot_w64(rm[r]) ? k0 : NEG_KEY;
             k1 = __builtin_amdgcn_inverse_ballot_w64(rm[r + 1]) ? k1 : NEG_KEY;
@@ -438,8 +453,8 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
 #pragma unroll
                     for (int s = 0; s < 8; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(base + 1024 * s);
                 }
-                const f32x16 two = {2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f};
-                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], two, 0, 0, 0);
+                const f32x16 four = {4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f};
+                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], four, 0, 0, 0);
 #pragma unroll
                 for (int s = 1; s < ABL_MFMA_STEPS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], bfr[s], acc, 0, 0, 0);
 #ifndef ABL_NOHOIST
@@ -460,12 +475,13 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
 #ifdef ABL_NOEPI
                 asm volatile("" ::"v"(acc));
 #else
-                const bool colok = (wB >> c) & 1u;
-                const int rmask = colok ? ~7 : 0, rtag = colok ? bt : NEG_KEY;
-                if (fresh) row_keys<true>(acc, KM, rmask, rtag);
-                else row_keys<false>(acc, KM, rmask, rtag);
+                int key[16];
+                make_keys(acc, key, bt << 4);
+                if (wB != 0xffffffffu) mask_keys(key, ((unsigned long long)wB << 32) | wB);
+                if (fresh) row_fold<true>(key, KM);
+                else row_fold<false>(key, KM);
                 fresh = false;
-                const int cb = apart ? col_keys<true>(acc, rm) : col_keys<false>(acc, rm);
+                const int cb = apart ? col_max<true>(key, rm) : col_max<false>(key, rm);
                 atomicMax(&col64[((par2 * SE + q) * 2 + slot_isel) * 32 + c], ((long long)cb << 32) | (long long)((slot_at << 1) | h));
 #endif
                 STAMP(3);
@@ -506,12 +522,12 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 // every lane of both halves now holds row `c` of the tile: key m, winning lane cc
                 const bool valid = (wA >> c) & 1u;
                 const bool none = m < 0;
-                const float val = none ? -FLT_MAX : __int_as_float(and_or_i(m, ~7, 4)) - 2.0f;
+                const float val = none ? -FLT_MAX : key_value(m);
                 const float rs = half32_sum(valid ? val : 0.f);
                 if (lane == 0) rowp[(par3 * SE + q) * 16 + slot_isel * 8 + slot_at] = rs;
                 if (h == 0 && p.argA)
                     p.argA[((size_t)ISEQ(slot_isel) * p.Bc + j_begin + (int)(mz & 0xff)) * p.TAp + slot_at * 32 + c] =
-                        (none || !valid) ? (uint16_t)0 : (uint16_t)((m & 7) * 32 + cc);
+                        (none || !valid) ? (uint16_t)0 : (uint16_t)(((m >> 4) & 7) * 32 + cc);
                 STAMP(4);
             }
         }
@@ -544,7 +560,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                     if (hi < 0) {
                         cv = -FLT_MAX;
                     } else {
-                        cv = __int_as_float(and_or_i(hi, ~15, 8)) - 2.0f;
+                        cv = key_value(hi);
                         barg = (lo >> 1) * 32 + acc_row(hi & 15, lo & 1);
                     }
                     if (p.argB)

@@ -273,21 +273,21 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         if (jl < nj) {
             nb_l[jl] = ntok;
             if (nvt == 0) {
-                meta[pos] = make_uint4(0u, 0u, (uint32_t)jl, FLAG_LAST);
+                meta[pos] = make_uint4(0u, 0u, (uint32_t)jl | (FLAG_LAST << 16), FLAG_LAST);
             } else {
                 int seen = 0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (wd[k]) {
                         ++seen;
-                        meta[pos++] = make_uint4(wd[k], (uint32_t)((j_begin + jl) * ntB + k), (uint32_t)(jl | (k << 8)),
+                        meta[pos++] = make_uint4(wd[k], (uint32_t)((j_begin + jl) * ntB + k), (uint32_t)(jl | (k << 8)) | ((seen == nvt ? FLAG_LAST : 0u) << 16),
                                                  seen == nvt ? FLAG_LAST : 0u);
                     }
             }
         }
         const int total = __shfl(incl, 63);
         const int padded = (total + SE - 1) / SE * SE;
-        if (lane < padded - total) meta[total + lane] = make_uint4(0u, 0u, 0u, FLAG_NULL);
+        if (lane < padded - total) meta[total + lane] = make_uint4(0u, 0u, FLAG_NULL << 16, FLAG_NULL);
         if (lane == 0) cnt_l[0] = padded;
     }
     __syncthreads();
@@ -424,19 +424,18 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         const int par2 = e & 1, par3 = e % 3;
 
         // this epoch's tile records, as scalars
-        uint32_t t_wB[SE], t_mz[SE], t_fl[SE];
+        uint32_t t_wB[SE], t_mz[SE];   // column mask; B sequence | B tile << 8 | flags << 16
 #pragma unroll
         for (int q = 0; q < SE; ++q) {
             const uint4 mraw = meta[e * SE + q];
             t_wB[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mraw.x);
             t_mz[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mraw.z);
-            t_fl[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mraw.w);
         }
         STAMP(1);
 
 #pragma unroll
         for (int q = 0; q < SE; ++q) {
-            const uint32_t wB = t_wB[q], mz = t_mz[q], fl = t_fl[q];
+            const uint32_t wB = t_wB[q], mz = t_mz[q], fl = mz >> 16;
             const int bt = (mz >> 8) & 7;
             // Issue priority by progress: of the four waves on a SIMD the one that is furthest behind
             // in the epoch goes first.  Left alone the SIMD serves its oldest wave first, the waves
@@ -504,20 +503,21 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                // All sixteen keys of a row carry the same register tag in their low four bits: it is
+                // replaced by 15 - column, so that the maximum brings its (lowest) column along.
+#pragma unroll
+                for (int k = 0; k < 16; ++k) k16[k] = and_or_i(k16[k], ~15, 15 - k);
                 const int a0 = max3_i(k16[0], k16[1], k16[2]), a1 = max3_i(k16[3], k16[4], k16[5]), a2 = max3_i(k16[6], k16[7], k16[8]);
                 const int a3 = max3_i(k16[9], k16[10], k16[11]), a4 = max3_i(k16[12], k16[13], k16[14]);
                 int m = max(max3_i(a0, a1, a2), max3_i(a3, a4, k16[15]));
                 m = empty_b ? NEG_KEY : m;
-                int cc = 15;
-#pragma unroll
-                for (int k = 14; k >= 0; --k) cc = (k16[k] == m) ? k : cc;
-                cc += 16 * h;
+                int cc;
                 {
-                    // the lower half holds the lower columns: it wins ties
-                    const int om = __shfl_xor(m, 32), oc = __shfl_xor(cc, 32);
+                    // the other half's best; on equal keys the lower half (the lower columns) wins
+                    const int om = __shfl_xor(m, 32);
                     const bool take = om + h > m;
                     m = take ? om : m;
-                    cc = take ? oc : cc;
+                    cc = 15 - (m & 15) + 16 * (take ? 1 - h : h);
                 }
                 // every lane of both halves now holds row `c` of the tile: key m, winning lane cc
                 const bool valid = (wA >> c) & 1u;

@@ -593,3 +593,22 @@ def test_filip_fused_backward_equals_the_two_calls(K, monkeypatch, window_kb):
         for a, b in zip(got, want):
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
     monkeypatch.delenv("PCLIP_FILIP_BWD_WINDOW_KB", raising=False)
+
+
+def test_filip_scores_do_not_depend_on_the_workgroup_count():
+    """The streaming kernel cuts the B side into chunks by a workgroup target (512 by default,
+    PCLIP_FILIP_STREAM_WGS, read once per process): scores and arg-max tables are bit-identical
+    for every cut (child processes, one per setting)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = []
+    for wgs in ("1", "40", "512", "5000"):
+        env = dict(os.environ, PCLIP_FILIP_STREAM_WGS=wgs)
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_wgs_check.py")], capture_output=True, text=True, timeout=200,
+                             cwd=root, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines.append([l for l in res.stdout.splitlines() if l.startswith("checksum")][-1])
+    assert len(set(lines)) == 1, lines
+

@@ -17,8 +17,8 @@
 // (the lowest exponent bit and all 23 mantissa bits stay) and the low seven bits are free for
 // the arg index: 3 bits of B tile for the row maxima, 4 bits of accumulator register for the
 // column maxima, ONE key per element for both sides (one v_lshl_or_b32).  Row and column
-// maxima are integer maxima of these keys; nothing of the value is dropped, a score differs
-// from the exact maximum only by the f32 rounding of the accumulation near 4 (<= 1e-6).
+// maxima are integer maxima of these keys; nothing of the value is dropped, a maximum differs
+// from the exact one only by the f32 rounding of the accumulation near 4 (ulp 2.4e-7 / 4.8e-7).
 // Padding columns and rows get a negative key.  Column maxima of the A tiles held by different waves
 // meet in LDS through a
 // 64-bit integer atomic max (key in the high word, A tile and lane half in the low word).

@@ -48,7 +48,6 @@ unsigned long long* g_stream_dbg = nullptr;
 
 #define NEG_KEY ((int)0xFF7FFFFF)              // bits of -FLT_MAX
 #define NEG_KEY64 ((long long)0x8000000000000000LL)
-#define TWO_BITS 0x40000000
 
 #define FLAG_LAST 1u
 #define FLAG_NULL 2u

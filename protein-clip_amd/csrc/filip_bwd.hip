@@ -44,16 +44,27 @@ struct FilipBwdArgs {
     int win0, accumulate;  // gather launch: first window it covers; add to the partials instead of overwriting
 };
 
-// inverse valid-token counts of every sequence, both sides in one launch
-__global__ __launch_bounds__(256) void filip_count_kernel(const uint32_t* __restrict__ mwA, int nA, int ntA, float* __restrict__ icA,
-                                                          const uint32_t* __restrict__ mwB, int nB, int ntB, float* __restrict__ icB) {
-    int s = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t* mw = mwA;
-    float* ic = icA;
-    int nt = ntA;
-    if (s >= nA) {
-        s -= nA; mw = mwB; ic = icB; nt = ntB;
-        if (s >= nB) return;
+// ---- the small jobs in front of the gathers, ONE launch (they are 4-6 us each as launches of
+// their own): blocks [0, nC) count tokens, [nC, nC + nT) transpose the upstream gradients,
+// the rest add up dt.
+struct BwdPreArgs {
+    const uint32_t* mwA; const uint32_t* mwB; int nA, ntA, nB, ntB;   // count: inverse valid-token counts
+    float* icA; float* icB;
+    const float* gA; const float* gB; int R, C;                        // transpose: [R][C] -> [C][R], both matrices
+    float* gAT; float* gBT;
+    const float* sA; const float* sB; const float* t; float* dt;       // dt += -(1/t) * sum(gA*sA + gB*sB)
+    int nC, nT, nD, tiles_x;
+};
+
+// inverse valid-token counts of every sequence, both sides
+__device__ __forceinline__ void pre_count(const BwdPreArgs& p, int blk) {
+    int s = blk * 256 + threadIdx.x;
+    const uint32_t* mw = p.mwA;
+    float* ic = p.icA;
+    int nt = p.ntA;
+    if (s >= p.nA) {
+        s -= p.nA; mw = p.mwB; ic = p.icB; nt = p.ntB;
+        if (s >= p.nB) return;
     }
     int c = 0;
     for (int k = 0; k < nt; ++k) c += __popc(mw[(size_t)s * nt + k]);
@@ -62,25 +73,46 @@ __global__ __launch_bounds__(256) void filip_count_kernel(const uint32_t* __rest
 
 // [R][C] -> [C][R] for the two upstream-gradient matrices at once (tiny: the B-side pass reads
 // them partner-contiguous, as the A-side pass reads the originals)
-__global__ __launch_bounds__(256) void filip_transpose2_kernel(const float* __restrict__ a, const float* __restrict__ b, int R, int C,
-                                                               float* __restrict__ aT, float* __restrict__ bT) {
-    __shared__ float tile[2][32][33];
+__device__ __forceinline__ void pre_transpose(const BwdPreArgs& p, int blk, float (&tile)[2][32][33]) {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int by = blk / p.tiles_x, bx = blk - by * p.tiles_x;
+    const int r0 = by * 32, c0 = bx * 32;
+    const int R = p.R, C = p.C;
     for (int k = ty; k < 32; k += 8) {
         const int r = r0 + k, c = c0 + tx;
         const bool in = r < R && c < C;
-        tile[0][k][tx] = in ? a[(size_t)r * C + c] : 0.f;
-        tile[1][k][tx] = in ? b[(size_t)r * C + c] : 0.f;
+        tile[0][k][tx] = in ? p.gA[(size_t)r * C + c] : 0.f;
+        tile[1][k][tx] = in ? p.gB[(size_t)r * C + c] : 0.f;
     }
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
         const int c = c0 + k, r = r0 + tx;
         if (r < R && c < C) {
-            aT[(size_t)c * R + r] = tile[0][tx][k];
-            bT[(size_t)c * R + r] = tile[1][tx][k];
+            p.gAT[(size_t)c * R + r] = tile[0][tx][k];
+            p.gBT[(size_t)c * R + r] = tile[1][tx][k];
         }
     }
+}
+
+// dt += -(1/t) * sum(gA*simA + gB*simB); pairs whose partner is empty hold infinities in the
+// reference too and are left out.
+__device__ __forceinline__ void pre_dt(const BwdPreArgs& p, int blk, float (&red)[4]) {
+    const size_t n = (size_t)p.R * p.C;
+    float acc = 0.f;
+    for (size_t k = (size_t)blk * 256 + threadIdx.x; k < n; k += (size_t)p.nD * 256) acc += p.gA[k] * p.sA[k] + p.gB[k] * p.sB[k];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(p.dt, -(red[0] + red[1] + red[2] + red[3]) / p.t[0]);
+}
+
+__global__ __launch_bounds__(256) void filip_bwd_pre_kernel(BwdPreArgs p) {
+    __shared__ float tile[2][32][33];
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    if (b < p.nC) pre_count(p, b);
+    else if (b < p.nC + p.nT) pre_transpose(p, b - p.nC, tile);
+    else pre_dt(p, b - p.nC - p.nT, red);
 }
 
 // One workgroup per (own sequence, partner window): counting sort of the window's valid partner
@@ -268,20 +300,6 @@ __global__ __launch_bounds__(256) void filip_window_sum_kernel(const float4* __r
     out[k] = s;
 }
 
-// dt += -(1/t) * sum(gA*simA + gB*simB); pairs whose partner is empty hold infinities in the
-// reference too and are left out.
-__global__ __launch_bounds__(256) void filip_dt_kernel(const float* __restrict__ gA, const float* __restrict__ gB, const float* __restrict__ sA,
-                                                       const float* __restrict__ sB, size_t n, const float* __restrict__ t,
-                                                       float* __restrict__ dt) {
-    __shared__ float red[4];
-    float acc = 0.f;
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) acc += gA[k] * sA[k] + gB[k] * sB[k];
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dt, -(red[0] + red[1] + red[2] + red[3]) / t[0]);
-}
-
 // ---- host side -------------------------------------------------------------------------
 static inline int tp32(int T) { return (T + 31) / 32 * 32; }
 
@@ -388,11 +406,21 @@ static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
     char* w = (char*)ws;
     float* icA = (float*)(w + L.icA);
     float* icB = (float*)(w + L.icB);
-    hipLaunchKernelGGL(filip_count_kernel, dim3((Br + Bc + 255) / 256), dim3(256), 0, st, maskwA, Br, TAp / 32, icA, maskwB, Bc, TBp / 32, icB);
     float* gAT = (float*)(w + L.gT);
     float* gBT = gAT + (size_t)Br * Bc;
-    if (dnB)
-        hipLaunchKernelGGL(filip_transpose2_kernel, dim3((Bc + 31) / 32, (Br + 31) / 32), dim3(256), 0, st, gA, gB, Br, Bc, gAT, gBT);
+    {
+        BwdPreArgs q;
+        q.mwA = maskwA; q.mwB = maskwB; q.nA = Br; q.ntA = TAp / 32; q.nB = Bc; q.ntB = TBp / 32; q.icA = icA; q.icB = icB;
+        q.gA = gA; q.gB = gB; q.R = Br; q.C = Bc; q.gAT = gAT; q.gBT = gBT;
+        q.sA = sim_A; q.sB = sim_B; q.t = t; q.dt = dt;
+        q.nC = (Br + Bc + 255) / 256;
+        q.tiles_x = (Bc + 31) / 32;
+        q.nT = dnB ? q.tiles_x * ((Br + 31) / 32) : 0;            // the transposed copies serve the B side
+        const size_t n = (size_t)Br * Bc;
+        q.nD = dnA ? (int)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256) : 0;   // dt goes with the A side
+        hipLaunchKernelGGL(filip_bwd_pre_kernel, dim3(q.nC + q.nT + q.nD), dim3(256), 0, st, q);
+        if (int rc = pclip_check_launch("filip_bwd_pre_kernel")) return rc;
+    }
     FilipBwdArgs a, b;
     // gradient of the A images: own = A(i), partner = B(j), pair = i*Bc + j
     a.hnP = hnB; a.mwO = maskwA; a.mwP = maskwB; a.No = Br; a.TOp = TAp; a.Np = Bc; a.TPp = TBp;
@@ -423,11 +451,7 @@ static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
             return rc;
         if (int rc = pclip_check_launch(side == 0 ? "filip backward (A side)" : "filip backward (B side)")) return rc;
     }
-    const size_t n = (size_t)Br * Bc;
-    const int blocks = (int)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
-    if (!dnA) return PCLIP_OK;   // dt goes with the A side
-    hipLaunchKernelGGL(filip_dt_kernel, dim3(blocks), dim3(256), 0, st, gA, gB, sim_A, sim_B, n, t, dt);
-    return pclip_check_launch("filip_dt_kernel");
+    return PCLIP_OK;
 }
 
 extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,

@@ -158,7 +158,7 @@ int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, i
  * as a device scalar (the kernel uses 1/|t|; the sign was folded into hnA by prep).
  * unit_norm != 0 asserts that every token row has L2 norm <= 1 (prep with normalise = 1):
  * the kernel then keeps value and arg-max in one integer maximum per element (exact up to the
- * f32 rounding of an accumulation that starts at 4.0: maxima within 1e-6, near-ties closer than
+ * f32 rounding of an accumulation that starts at 4.0: maxima within 2e-6, near-ties closer than
  * that may pick either token); unit_norm = 0 makes no assumption (exact f32 maxima, slower).
  *   sim_A, sim_B [Br,Bc] f32
  *   argA [Br,Bc,TAp] u16: for each valid a the b attaining the max

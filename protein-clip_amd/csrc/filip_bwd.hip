@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void filip_bwd_pre_kernel(BwdPreArgs p) {
 // Dynamic LDS: TOp counters, then `stage` entries.
 #define INV_THREADS 512
 #define INV_STAGE_MAX 24576   // entries (96 KB)
+#define INV_KEEP 2            // 8-entry vectors a thread keeps in registers between the two passes
 __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs p, int stage) {
     extern __shared__ int hist[];                        // [own token] counts, then bucket cursors
     __shared__ int wsum[INV_THREADS / 64];
@@ -139,11 +140,20 @@ __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs 
     __syncthreads();
     const bool own_live = p.icO[o] > 0.f;
     const int nvec = (own_live && q_hi > q_lo) ? (q_hi - q_lo) * vpr : 0;
-    for (int v = tid; v < nvec; v += INV_THREADS) {
+    // the first INV_KEEP vectors of a thread stay in registers for the second pass (a 2-MB window
+    // of 256-token partners is exactly two per thread), later ones are read again
+    uint4 keep_d[INV_KEEP];
+    uint32_t keep_m[INV_KEEP];
+#pragma unroll
+    for (int u = 0; u < INV_KEEP; ++u) keep_m[u] = 0u;
+    for (int v = tid, u = 0; v < nvec; v += INV_THREADS, ++u) {
         const int ql = v / vpr, pt0 = (v - ql * vpr) * 8, q = q_lo + ql;
         const uint32_t m8 = (p.mwP[(size_t)q * ntP + (pt0 >> 5)] >> (pt0 & 31)) & 0xffu;
         if (m8 == 0) continue;
         const uint4 d = *reinterpret_cast<const uint4*>(p.arg2 + ((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt0);
+#pragma unroll
+        for (int uu = 0; uu < INV_KEEP; ++uu)
+            if (uu == u) { keep_d[uu] = d; keep_m[uu] = m8; }
         const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -182,11 +192,22 @@ __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs 
     }
     __syncthreads();
     uint32_t* dst = stage ? sorted : list;   // LDS stage or straight to global memory
-    for (int v = tid; v < nvec; v += INV_THREADS) {
+    for (int v = tid, u = 0; v < nvec; v += INV_THREADS, ++u) {
         const int ql = v / vpr, pt0 = (v - ql * vpr) * 8, q = q_lo + ql;
-        const uint32_t m8 = (p.mwP[(size_t)q * ntP + (pt0 >> 5)] >> (pt0 & 31)) & 0xffu;
-        if (m8 == 0) continue;
-        const uint4 d = *reinterpret_cast<const uint4*>(p.arg2 + ((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt0);
+        uint32_t m8;
+        uint4 d;
+        if (u < INV_KEEP) {
+            m8 = 0u;
+            d = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int uu = 0; uu < INV_KEEP; ++uu)
+                if (uu == u) { d = keep_d[uu]; m8 = keep_m[uu]; }
+            if (m8 == 0) continue;
+        } else {
+            m8 = (p.mwP[(size_t)q * ntP + (pt0 >> 5)] >> (pt0 & 31)) & 0xffu;
+            if (m8 == 0) continue;
+            d = *reinterpret_cast<const uint4*>(p.arg2 + ((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt0);
+        }
         const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
         for (int k = 0; k < 8; ++k)

@@ -29,6 +29,8 @@ struct FilipBwdArgs {
     int No, TOp, Np, TPp;
     const uint16_t* arg1;  // [pair][TOp]  partner token chosen by each own token
     const uint16_t* arg2;  // [pair][TPp]  own token chosen by each partner token
+    const uint32_t* mut1;  // [pair][TOp/32] bit a: own token a and the partner token it chose chose each other
+    const uint32_t* mut2;  // [pair][TPp/32] the same for the partner tokens
     const float* g1;       // [pair] d loss / d score averaged over OWN tokens
     const float* g2;       // [pair] d loss / d score averaged over PARTNER tokens
     size_t so, sp;         // pair index into arg1 / arg2 = own*so + partner*sp
@@ -115,6 +117,69 @@ __global__ __launch_bounds__(256) void filip_bwd_pre_kernel(BwdPreArgs p) {
     else pre_dt(p, b - p.nC - p.nT, red);
 }
 
+// A token pair (a, b) of a sequence pair that chose each other appears twice in the routing,
+// with the same partner row: once as a's choice, once in the bucket of the tokens that chose a.
+// About half of all tokens of random unit vectors are in such pairs.  This kernel marks them
+// (one bit per token and sequence pair, both sides); the inversion then leaves them out of the
+// buckets and the gather adds the second weight to the first fetch: a quarter fewer rows.
+// One wave per sequence pair; the two arg rows sit in LDS for the cross look-ups.
+__global__ __launch_bounds__(256) void filip_mutual_kernel(const uint16_t* __restrict__ argA, const uint16_t* __restrict__ argB,
+                                                           const uint32_t* __restrict__ mwA, const uint32_t* __restrict__ mwB, int Br, int Bc,
+                                                           int TAp, int TBp, uint32_t* __restrict__ mutA, uint32_t* __restrict__ mutB) {
+    extern __shared__ uint16_t sh16[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t pair = (size_t)blockIdx.x * 4 + w;
+    if (pair >= (size_t)Br * Bc) return;
+    const int i = (int)(pair / Bc), j = (int)(pair - (size_t)i * Bc);
+    uint16_t* a_l = sh16 + (size_t)w * (TAp + TBp);
+    uint16_t* b_l = a_l + TAp;
+    const uint16_t* ga = argA + pair * TAp;
+    const uint16_t* gb = argB + pair * TBp;
+    const uint32_t* ma = mwA + (size_t)i * (TAp >> 5);
+    const uint32_t* mb = mwB + (size_t)j * (TBp >> 5);
+    // entries of padding tokens are unspecified: they enter as an index that matches nothing
+    // (four entries per lane and load; Tp is a multiple of 32, so the rows are 8-byte aligned)
+    for (int k = 4 * lane; k < TAp; k += 256) {
+        const uint2 v = *reinterpret_cast<const uint2*>(ga + k);
+        const uint32_t m4 = ma[k >> 5] >> (k & 31);
+        const uint32_t lo = ((m4 & 1u) ? (v.x & 0xffffu) : 0xffffu) | ((m4 & 2u) ? (v.x & 0xffff0000u) : 0xffff0000u);
+        const uint32_t hi = ((m4 & 4u) ? (v.y & 0xffffu) : 0xffffu) | ((m4 & 8u) ? (v.y & 0xffff0000u) : 0xffff0000u);
+        *reinterpret_cast<uint2*>(a_l + k) = make_uint2(lo, hi);
+    }
+    for (int k = 4 * lane; k < TBp; k += 256) {
+        const uint2 v = *reinterpret_cast<const uint2*>(gb + k);
+        const uint32_t m4 = mb[k >> 5] >> (k & 31);
+        const uint32_t lo = ((m4 & 1u) ? (v.x & 0xffffu) : 0xffffu) | ((m4 & 2u) ? (v.x & 0xffff0000u) : 0xffff0000u);
+        const uint32_t hi = ((m4 & 4u) ? (v.y & 0xffffu) : 0xffffu) | ((m4 & 8u) ? (v.y & 0xffff0000u) : 0xffff0000u);
+        *reinterpret_cast<uint2*>(b_l + k) = make_uint2(lo, hi);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    // 256 tokens at a time, so that the four dependent LDS look-ups of a lane overlap
+    auto mark = [&](const uint16_t* own, int TOp, const uint16_t* oth, int TPp, uint32_t* out) {
+        for (int base = 0; base < TOp; base += 256) {
+            int x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = base + 64 * u + lane;
+                x[u] = k < TOp ? (int)own[k] : 0xffff;
+            }
+            bool m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m[u] = x[u] < TPp && (int)oth[x[u] < TPp ? x[u] : 0] == base + 64 * u + lane;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k0 = base + 64 * u;
+                const unsigned long long bal = __ballot(m[u]);
+                if (k0 < TOp && lane == 0) out[k0 >> 5] = (uint32_t)bal;
+                if (k0 + 32 < TOp && lane == 32) out[(k0 >> 5) + 1] = (uint32_t)(bal >> 32);
+            }
+        }
+    };
+    mark(a_l, TAp, b_l, TBp, mutA + pair * (TAp >> 5));
+    mark(b_l, TBp, a_l, TAp, mutB + pair * (TBp >> 5));
+}
+
 // One workgroup per (own sequence, partner window): counting sort of the window's valid partner
 // tokens by the own token they chose.  Eight u16 entries are read per 16-byte load; the sorted
 // entries are built in LDS and leave as one coalesced copy (scattered 4-byte stores to global
@@ -148,9 +213,11 @@ __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs 
     for (int u = 0; u < INV_KEEP; ++u) keep_m[u] = 0u;
     for (int v = tid, u = 0; v < nvec; v += INV_THREADS, ++u) {
         const int ql = v / vpr, pt0 = (v - ql * vpr) * 8, q = q_lo + ql;
-        const uint32_t m8 = (p.mwP[(size_t)q * ntP + (pt0 >> 5)] >> (pt0 & 31)) & 0xffu;
+        const size_t pair = (size_t)o * p.so + (size_t)q * p.sp;
+        // valid partner tokens whose choice is not mutual (those ride on the own token's fetch)
+        const uint32_t m8 = ((p.mwP[(size_t)q * ntP + (pt0 >> 5)] & ~p.mut2[pair * ntP + (pt0 >> 5)]) >> (pt0 & 31)) & 0xffu;
         if (m8 == 0) continue;
-        const uint4 d = *reinterpret_cast<const uint4*>(p.arg2 + ((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt0);
+        const uint4 d = *reinterpret_cast<const uint4*>(p.arg2 + pair * p.TPp + pt0);
 #pragma unroll
         for (int uu = 0; uu < INV_KEEP; ++uu)
             if (uu == u) { keep_d[uu] = d; keep_m[uu] = m8; }
@@ -204,9 +271,10 @@ __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs 
                 if (uu == u) { d = keep_d[uu]; m8 = keep_m[uu]; }
             if (m8 == 0) continue;
         } else {
-            m8 = (p.mwP[(size_t)q * ntP + (pt0 >> 5)] >> (pt0 & 31)) & 0xffu;
+            const size_t pair = (size_t)o * p.so + (size_t)q * p.sp;
+            m8 = ((p.mwP[(size_t)q * ntP + (pt0 >> 5)] & ~p.mut2[pair * ntP + (pt0 >> 5)]) >> (pt0 & 31)) & 0xffu;
             if (m8 == 0) continue;
-            d = *reinterpret_cast<const uint4*>(p.arg2 + ((size_t)o * p.so + (size_t)q * p.sp) * p.TPp + pt0);
+            d = *reinterpret_cast<const uint4*>(p.arg2 + pair * p.TPp + pt0);
         }
         const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
@@ -254,7 +322,10 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
             if (q < q_hi) {
                 const size_t pair = (size_t)o * p.so + (size_t)q * p.sp;
                 b = p.arg1[pair * p.TOp + a];
-                w = p.icP[q] > 0.f ? p.g1[(size_t)o * p.gso + (size_t)q * p.gsp] * c1 : 0.f;
+                const float icq = p.icP[q];
+                w = icq > 0.f ? p.g1[(size_t)o * p.gso + (size_t)q * p.gsp] * c1 : 0.f;
+                // b chose a as well: its share of the partner-side term comes with this fetch
+                if ((p.mut1[pair * (p.TOp >> 5) + (a >> 5)] >> (a & 31)) & 1u) w += p.g2[(size_t)o * p.gso + (size_t)q * p.gsp] * icq * inv_t;
             }
             bf16x8 rows[16];
             float ws[16];
@@ -346,7 +417,7 @@ static BwdPlan bwd_plan(int Np, int TPp) {
 }
 
 struct BwdWs {
-    size_t listA, listB, segA, segB, icA, icB, gT, partA, partB, total;
+    size_t listA, listB, segA, segB, icA, icB, gT, mutA, mutB, partA, partB, total;
     size_t dnA, dnB, total_fused;   // fused entry: scratch dn of a side that runs as a single window
     BwdPlan planA, planB;   // A-side pass (partners = B) and B-side pass (partners = A)
 };
@@ -363,6 +434,8 @@ static BwdWs bwd_ws_layout(int Br, int TA, int Bc, int TB) {
     w.icA = off;   off += pclip_align_up((size_t)Br * 4, 256);
     w.icB = off;   off += pclip_align_up((size_t)Bc * 4, 256);
     w.gT = off;    off += pclip_align_up((size_t)2 * Br * Bc * 4, 256);   // transposed copies of gA, gB
+    w.mutA = off;  off += pclip_align_up((size_t)Br * Bc * (TAp / 32) * 4, 256);   // mutual-choice bits of the A tokens
+    w.mutB = off;  off += pclip_align_up((size_t)Br * Bc * (TBp / 32) * 4, 256);
     w.partA = off; off += w.planA.nwt > 1 ? pclip_align_up((size_t)BWD_XCDS * Br * TAp * FD * 4, 256) : 0;   // partials of dnA
     w.partB = off; off += w.planB.nwt > 1 ? pclip_align_up((size_t)BWD_XCDS * Bc * TBp * FD * 4, 256) : 0;
     w.total = off;
@@ -442,15 +515,32 @@ static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
         hipLaunchKernelGGL(filip_bwd_pre_kernel, dim3(q.nC + q.nT + q.nD), dim3(256), 0, st, q);
         if (int rc = pclip_check_launch("filip_bwd_pre_kernel")) return rc;
     }
+    uint32_t* mutA = (uint32_t*)(w + L.mutA);
+    uint32_t* mutB = (uint32_t*)(w + L.mutB);
+    {
+        const size_t lds = (size_t)4 * (TAp + TBp) * sizeof(uint16_t);
+        if (lds > 48 * 1024) {
+            static size_t raised = 0;
+            if (lds > raised) {
+                if (hipFuncSetAttribute((const void*)filip_mutual_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                    return pclip_fail(PCLIP_ELAUNCH, "filip_mutual_kernel: cannot raise the dynamic LDS limit");
+                raised = lds;
+            }
+        }
+        const size_t npair = (size_t)Br * Bc;
+        hipLaunchKernelGGL(filip_mutual_kernel, dim3((unsigned)((npair + 3) / 4)), dim3(256), lds, st, argA, argB, maskwA, maskwB, Br, Bc, TAp, TBp,
+                           mutA, mutB);
+        if (int rc = pclip_check_launch("filip_mutual_kernel")) return rc;
+    }
     FilipBwdArgs a, b;
     // gradient of the A images: own = A(i), partner = B(j), pair = i*Bc + j
     a.hnP = hnB; a.mwO = maskwA; a.mwP = maskwB; a.No = Br; a.TOp = TAp; a.Np = Bc; a.TPp = TBp;
-    a.arg1 = argA; a.arg2 = argB; a.g1 = gA; a.g2 = gB; a.so = (size_t)Bc; a.sp = 1; a.gso = (size_t)Bc; a.gsp = 1; a.t = t;
+    a.arg1 = argA; a.arg2 = argB; a.mut1 = mutA; a.mut2 = mutB; a.g1 = gA; a.g2 = gB; a.so = (size_t)Bc; a.sp = 1; a.gso = (size_t)Bc; a.gsp = 1; a.t = t;
     a.icO = icA; a.icP = icB; a.seg = (int*)(w + L.segA); a.list = (uint32_t*)(w + L.listA); a.dn = nullptr;
     a.nwt = L.planA.nwt; a.qpw = L.planA.qpw; a.win0 = 0; a.accumulate = 0;
     // gradient of the B images: own = B(j), partner = A(i), pair = i*Bc + j
     b.hnP = hnA; b.mwO = maskwB; b.mwP = maskwA; b.No = Bc; b.TOp = TBp; b.Np = Br; b.TPp = TAp;
-    b.arg1 = argB; b.arg2 = argA; b.g1 = gBT; b.g2 = gAT; b.so = 1; b.sp = (size_t)Bc; b.gso = (size_t)Br; b.gsp = 1; b.t = t;
+    b.arg1 = argB; b.arg2 = argA; b.mut1 = mutB; b.mut2 = mutA; b.g1 = gBT; b.g2 = gAT; b.so = 1; b.sp = (size_t)Bc; b.gso = (size_t)Br; b.gsp = 1; b.t = t;
     b.icO = icB; b.icP = icA; b.seg = (int*)(w + L.segB); b.list = (uint32_t*)(w + L.listB); b.dn = nullptr;
     b.nwt = L.planB.nwt; b.qpw = L.planB.qpw; b.win0 = 0; b.accumulate = 0;
     for (int side = 0; side < 2; ++side) {

@@ -360,7 +360,9 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
             for (int k = 0; k < 16; ++k) {
                 const uint32_t ek = __shfl(ent, k, 16);
                 ws[k] = __shfl(w, k, 16);
-                rows[k] = *reinterpret_cast<const bf16x8*>(p.hnP + ((size_t)(ek >> 16) * p.TPp + (ek & 0xffffu)) * FD + l16 * 8);
+                // a batch is 16 entries; the lanes past the bucket's end fetch nothing (2 % of the kernel)
+                if (pos0 + k < end) rows[k] = *reinterpret_cast<const bf16x8*>(p.hnP + ((size_t)(ek >> 16) * p.TPp + (ek & 0xffffu)) * FD + l16 * 8);
+                else rows[k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k)

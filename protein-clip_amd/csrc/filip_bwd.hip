@@ -167,13 +167,14 @@ __global__ __launch_bounds__(256) void filip_mutual_kernel(const uint16_t* __res
             bool m[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) m[u] = x[u] < TPp && (int)oth[x[u] < TPp ? x[u] : 0] == base + 64 * u + lane;
+            // the eight words of the 256 tokens leave as one store: lane l holds word l
+            uint32_t word = 0u;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int k0 = base + 64 * u;
                 const unsigned long long bal = __ballot(m[u]);
-                if (k0 < TOp && lane == 0) out[k0 >> 5] = (uint32_t)bal;
-                if (k0 + 32 < TOp && lane == 32) out[(k0 >> 5) + 1] = (uint32_t)(bal >> 32);
+                word = lane == 2 * u ? (uint32_t)bal : lane == 2 * u + 1 ? (uint32_t)(bal >> 32) : word;
             }
+            if (lane < 8 && base + 32 * lane < TOp) out[(base >> 5) + lane] = word;
         }
     };
     mark(a_l, TAp, b_l, TBp, mutA + pair * (TAp >> 5));

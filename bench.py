@@ -37,8 +37,9 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # a step is under 2 ms and the GPU needs about 15 of them to reach its steady clocks
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", choices=["both", "clip", "filip"], default="both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-length", action="store_true",

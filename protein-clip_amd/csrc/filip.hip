@@ -58,10 +58,10 @@ __global__ __launch_bounds__(256) void filip_prep_kernel(const float* __restrict
 // Masked and padding tokens carry a zero dn (the score backward never touches them), so
 // their dh comes out zero without consulting the mask.
 __global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dn, int nslab,
-                                                             size_t slab_stride, const uint32_t* __restrict__ mw, int B, int T, int d,
+                                                             size_t slab_stride, size_t row_stride, const uint32_t* __restrict__ mw, int B, int T, int d,
                                                              int Tp, int normalise, const float* __restrict__ tsign, int accumulate,
                                                              float* __restrict__ dh) {
-    // dn is the sum of `nslab` slabs `slab_stride` floats apart (the partial gradients of the
+    // dn is the sum of `nslab` slabs `slab_stride` floats apart, rows `row_stride` floats apart (the partial gradients of the
     // windowed backward); with mask words given, rows of padding tokens are taken as zero
     // without being read.
     const bool negate = tsign && tsign[0] < 0.f;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __rest
     if (row >= (size_t)B * T) return;
     const int seq = (int)(row / T), tok = (int)(row - (size_t)seq * T);
     const float* hr = h + row * d;
-    const float* gr = dn + ((size_t)seq * Tp + tok) * FD;
+    const float* gr = dn + ((size_t)seq * Tp + tok) * row_stride;
     float* out = dh + row * d;
     const int k = 2 * lane;
     const bool live = !mw || ((mw[(size_t)seq * (Tp >> 5) + (tok >> 5)] >> (tok & 31)) & 1u);
@@ -110,11 +110,11 @@ __global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __rest
 }
 
 // internal: prep backward over a sum of slabs (used by the fused backward of filip_bwd.hip)
-int filip_prep_bwd_launch(const float* h, const float* dn, int nslab, size_t slab_stride, const uint32_t* mw, int B, int T, int d,
+int filip_prep_bwd_launch(const float* h, const float* dn, int nslab, size_t slab_stride, size_t row_stride, const uint32_t* mw, int B, int T, int d,
                           int normalise, const float* tsign, int accumulate, float* dh, void* stream) {
     const int Tp = (T + 31) / 32 * 32;
     const size_t rows = (size_t)B * T;
-    hipLaunchKernelGGL(filip_prep_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, dn, nslab, slab_stride, mw,
+    hipLaunchKernelGGL(filip_prep_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, dn, nslab, slab_stride, row_stride, mw,
                        B, T, d, Tp, normalise, tsign, accumulate, dh);
     return pclip_check_launch("filip_prep_bwd_kernel");
 }
@@ -316,7 +316,7 @@ extern "C" int pclip_filip_prep_bwd(const float* h, const float* dn, int B, int 
                                     float* dh, void* stream) {
     PCLIP_REQUIRE(h && dn && dh, "filip_prep_bwd: null pointer");
     if (int rc = filip_dims_ok("filip_prep_bwd", B, T, d)) return rc;
-    return filip_prep_bwd_launch(h, dn, 1, 0, nullptr, B, T, d, normalise, tsign, accumulate, dh, stream);
+    return filip_prep_bwd_launch(h, dn, 1, 0, FD, nullptr, B, T, d, normalise, tsign, accumulate, dh, stream);
 }
 
 extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,

@@ -68,5 +68,5 @@ int l2norm_scale_fwd_pair_launch(const float* e0, const float* e1, const float* 
 int l2norm_scale_bwd_pair_launch(const float* e0, const float* e1, const float* t, const float* dx0, const float* dx1, int nslab,
                                  size_t slab_stride, float* de0, float* de1, float* dt, int B, int d, void* stream);
 // internal launcher of the prep backward over a sum of gradient slabs (filip.hip)
-int filip_prep_bwd_launch(const float* h, const float* dn, int nslab, size_t slab_stride, const uint32_t* mw, int B, int T, int d,
+int filip_prep_bwd_launch(const float* h, const float* dn, int nslab, size_t slab_stride, size_t row_stride, const uint32_t* mw, int B, int T, int d,
                           int normalise, const float* tsign, int accumulate, float* dh, void* stream);

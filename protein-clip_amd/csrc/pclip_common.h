@@ -42,9 +42,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // Row of a 32x32 MFMA accumulator tile held in register `reg` (0..15) by lane half `h` (0/1).
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// Sum over the 64 lanes, result in every lane: four DPP steps inside each row of 16 lanes (no
+// LDS round trip), then two cross-row exchanges.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+#define PCLIP_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+    PCLIP_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    PCLIP_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    PCLIP_DPP_ADD(0x141);  // row_half_mirror
+    PCLIP_DPP_ADD(0x140);  // row_mirror
+#undef PCLIP_DPP_ADD
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {

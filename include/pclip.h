@@ -160,15 +160,14 @@ int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, i
  * the kernel then keeps value and arg-max in one integer maximum per element (exact up to the
  * f32 rounding of an accumulation that starts at 4.0: maxima within 2e-6, near-ties closer than
  * that may pick either token); unit_norm = 0 makes no assumption (exact f32 maxima, slower).
+ * A value of 2 or more is unit_norm = 1 with that number of workgroups aimed at per launch
+ * instead of the default of 512 (tuning and tests; results do not depend on it).
  *   sim_A, sim_B [Br,Bc] f32
  *   argA [Br,Bc,TAp] u16: for each valid a the b attaining the max
  *   argB [Br,Bc,TBp] u16: for each valid b the a attaining the max
  * (argA/argB feed the backward, which reads the entries of valid tokens only; entries of
  * padding tokens are unspecified and may be left unwritten.  Pass NULL for both to skip them
- * in inference.)  Setting the environment variable PCLIP_FILIP_KERNEL=old before the call
- * selects the earlier non-streaming unit-norm kernel (kept for A/B timing);
- * PCLIP_FILIP_STREAM_WGS=<n> (read once) overrides the number of workgroups the streaming
- * kernel aims at per launch (default 512).
+ * in inference.)
  * TA, TB <= PCLIP_FILIP_MAX_T_LONG; sequences beyond PCLIP_FILIP_MAX_T tokens (the reference keeps
  * chains of up to 2,000 residues, modules/data_utils_2protein.py:88) run on a general, untuned
  * kernel. */

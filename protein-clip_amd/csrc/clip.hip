@@ -303,13 +303,8 @@ static int clip_grad_launch(const float* X_own, const float* Y_own, const float*
     a.p[1] = ClipProb{Y_own, X_all, Br, Bg, row_offset, nullptr, nullptr, nullptr, nullptr, lse_col_all + row_offset, lse_row_all,
                       slab + (size_t)a.nsplit * Br * d};
     *nsplit_out = a.nsplit;
-    static bool lds_set = false;  // 66 KB of dynamic LDS is above the default 64 KB launch limit
-    if (!lds_set) {
-        if (hipFuncSetAttribute((const void*)clip_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 129 * sizeof(float)) !=
-            hipSuccess)
-            return pclip_fail(PCLIP_ELAUNCH, "clip_grad_kernel: cannot raise the dynamic LDS limit");
-        lds_set = true;
-    }
+    static PclipLdsLimit lds_limit;  // 66 KB of dynamic LDS is above the default launch limit
+    if (int rc = pclip_ensure_lds(lds_limit, (const void*)clip_grad_kernel, 4 * 32 * 129 * sizeof(float), "clip_grad_kernel")) return rc;
     hipLaunchKernelGGL(clip_grad_kernel, dim3((Br + 31) / 32, a.nsplit, 2), dim3(256), 4 * 32 * 129 * sizeof(float), st, a);
     return pclip_check_launch("clip_grad_kernel");
 }
@@ -356,7 +351,6 @@ extern "C" int pclip_clip_step(const float* e_pep, const float* e_rec, const flo
     void* cws = p;
     const size_t cws_bytes = pclip_clip_workspace_bytes(B, B, d);
     float* slab = (float*)(p + cws_bytes);
-    PCLIP_REQUIRE(d <= 4096, "clip_step: d=%d out of range", d);
     if (int rc = l2norm_scale_fwd_pair_launch(e_pep, e_rec, t, x, y, B, d, dt, stream)) return rc;   // also clears dt
     if (int rc = pclip_clip_fwd(x, y, x, y, B, B, d, 0, lse_row, lse_col, loss, nullptr, 0, cws, cws_bytes, stream)) return rc;
     int ns = 1;

@@ -8,7 +8,6 @@
 // running row maximum (elementwise, reduced across lanes once per pair) and a column
 // maximum (over registers) as soon as the tile leaves the matrix core.
 #include "pclip_common.h"
-#include <stdlib.h>
 
 #define FD 128            // padded embedding width
 #define ROWB (FD * 2)     // bytes per token row
@@ -329,14 +328,9 @@ extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, 
     if (TA > PCLIP_FILIP_MAX_T || TB > PCLIP_FILIP_MAX_T)
         return filip_sim_long_launch(hnA, maskwA, Br, (TA + 31) / 32 * 32, hnB, maskwB, Bc, (TB + 31) / 32 * 32, t, sim_A, sim_B, argA, argB,
                                      stream);
-    if (unit_norm) {
-        static const int which = [] { const char* e = getenv("PCLIP_FILIP_KERNEL"); return (e && e[0] == 'o') ? 0 : 1; }();
-        if (which)
-            return filip_sim_stream_launch(hnA, maskwA, Br, (TA + 31) / 32 * 32, hnB, maskwB, Bc, (TB + 31) / 32 * 32, t, sim_A, sim_B, argA,
-                                           argB, stream);
-        return filip_sim_unit_launch(hnA, maskwA, Br, (TA + 31) / 32 * 32, hnB, maskwB, Bc, (TB + 31) / 32 * 32, t, sim_A, sim_B, argA, argB,
-                                     stream);
-    }
+    if (unit_norm)
+        return filip_sim_stream_launch(hnA, maskwA, Br, (TA + 31) / 32 * 32, hnB, maskwB, Bc, (TB + 31) / 32 * 32, t, sim_A, sim_B, argA, argB,
+                                       unit_norm >= 2 ? unit_norm : 0, stream);
     FilipArgs a;
     a.hnA = hnA; a.mwA = maskwA; a.Br = Br; a.TAp = (TA + 31) / 32 * 32;
     a.hnB = hnB; a.mwB = maskwB; a.Bc = Bc; a.TBp = (TB + 31) / 32 * 32;
@@ -348,12 +342,8 @@ extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, 
     if (jchunk < 8) jchunk = Bc < 8 ? Bc : 8;
     nchunk = (Bc + jchunk - 1) / jchunk;
     a.jchunk = jchunk;
-    static bool lds_set = false;
-    if (!lds_set) {
-        if (hipFuncSetAttribute((const void*)filip_sim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
-            return pclip_fail(PCLIP_ELAUNCH, "filip_sim_kernel: cannot raise the dynamic LDS limit");
-        lds_set = true;
-    }
+    static PclipLdsLimit lds_limit;
+    if (int rc = pclip_ensure_lds(lds_limit, (const void*)filip_sim_kernel, LDS_TOTAL, "filip_sim_kernel")) return rc;
     hipLaunchKernelGGL(filip_sim_kernel, dim3(Br * nchunk), dim3(256), LDS_TOTAL, (hipStream_t)stream, a);
     return pclip_check_launch("filip_sim_kernel");
 }

@@ -525,14 +525,8 @@ static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
     uint32_t* mutB = (uint32_t*)(w + L.mutB);
     {
         const size_t lds = (size_t)4 * (TAp + TBp) * sizeof(uint16_t);
-        if (lds > 48 * 1024) {
-            static size_t raised = 0;
-            if (lds > raised) {
-                if (hipFuncSetAttribute((const void*)filip_mutual_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                    return pclip_fail(PCLIP_ELAUNCH, "filip_mutual_kernel: cannot raise the dynamic LDS limit");
-                raised = lds;
-            }
-        }
+        static PclipLdsLimit lds_limit;
+        if (int rc = pclip_ensure_lds(lds_limit, (const void*)filip_mutual_kernel, lds, "filip_mutual_kernel")) return rc;
         const size_t npair = (size_t)Br * Bc;
         hipLaunchKernelGGL(filip_mutual_kernel, dim3((unsigned)((npair + 3) / 4)), dim3(256), lds, st, argA, argB, maskwA, maskwB, Br, Bc, TAp, TBp,
                            mutA, mutB);
@@ -555,14 +549,8 @@ static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
         const size_t cap = (size_t)u.qpw * u.TPp;                       // entries of one window at most
         const int stage = cap <= INV_STAGE_MAX ? (int)cap : 0;
         const size_t lds = ((size_t)u.TOp + stage) * 4;
-        if (lds > 48 * 1024) {
-            static size_t raised = 0;
-            if (lds > raised) {
-                if (hipFuncSetAttribute((const void*)filip_invert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                    return pclip_fail(PCLIP_ELAUNCH, "filip_invert_kernel: cannot raise the dynamic LDS limit");
-                raised = lds;
-            }
-        }
+        static PclipLdsLimit lds_limit;
+        if (int rc = pclip_ensure_lds(lds_limit, (const void*)filip_invert_kernel, lds, "filip_invert_kernel")) return rc;
         hipLaunchKernelGGL(filip_invert_kernel, dim3((unsigned)((size_t)u.No * u.nwt)), dim3(INV_THREADS), lds, st, u, stage);
         if (int rc = bwd_gather_side(u, (float*)(w + (side == 0 ? L.partA : L.partB)), side == 0 ? dnA : dnB, side == 0 ? tailA : tailB, st))
             return rc;

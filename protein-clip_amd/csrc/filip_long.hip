@@ -154,14 +154,8 @@ int filip_sim_long_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
     a.hnB = hnB; a.mwB = maskwB; a.Bc = Bc; a.TBp = TBp;
     a.t = t; a.simA = sim_A; a.simB = sim_B; a.argA = argA; a.argB = argB;
     const size_t lds = (size_t)4 * TBp * sizeof(float2) + 8 * sizeof(float) + 2 * sizeof(int);
-    if (lds > 48 * 1024) {
-        static size_t raised = 0;
-        if (lds > raised) {
-            if (hipFuncSetAttribute((const void*)filip_sim_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return pclip_fail(PCLIP_ELAUNCH, "filip_sim_long_kernel: cannot raise the dynamic LDS limit");
-            raised = lds;
-        }
-    }
+    static PclipLdsLimit lds_limit;
+    if (int rc = pclip_ensure_lds(lds_limit, (const void*)filip_sim_long_kernel, lds, "filip_sim_long_kernel")) return rc;
     hipLaunchKernelGGL(filip_sim_long_kernel, dim3((unsigned)((size_t)Br * Bc)), dim3(256), lds, (hipStream_t)stream, a);
     return pclip_check_launch("filip_sim_long_kernel");
 }

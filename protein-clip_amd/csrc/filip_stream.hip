@@ -25,7 +25,6 @@
 // Rows finish once per (A tile, B sequence) by transposing the 32x32 keys through a per-wave
 // LDS pad; columns finish once per epoch, after its barrier, by a rotating subset of waves.
 #include "pclip_common.h"
-#include <stdlib.h>
 
 // Diagnostic build (-DSTREAM_STAMPS): every wave adds up the shader-clock cycles it spends in
 // eight segments of the main loop and stores them to g_stream_dbg[(block*16 + wave)*8 + k].
@@ -584,7 +583,8 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
 }
 
 int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
-                            int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, void* stream) {
+                            int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int wgs_target,
+                            void* stream) {
     using C = StreamCfg;
     FilipStreamArgs a;
     a.hnA = hnA; a.mwA = maskwA; a.Br = Br; a.TAp = TAp;
@@ -594,24 +594,15 @@ int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br,
 #ifdef STREAM_STAMPS
     a.dbg = g_stream_dbg;
 #endif
-    static int wgs_target = 0;   // PCLIP_FILIP_STREAM_WGS overrides the default (tuning and tests)
-    if (wgs_target == 0) {
-        const char* e = getenv("PCLIP_FILIP_STREAM_WGS");
-        const int v = e ? atoi(e) : 0;
-        wgs_target = v >= 1 && v <= 65536 ? v : STREAM_WGS;
-    }
+    if (wgs_target < 1 || wgs_target > 65536) wgs_target = STREAM_WGS;
     int nchunk = (wgs_target + a.ngroups - 1) / a.ngroups;   // about two workgroups per CU over the launch
     int jchunk = (Bc + nchunk - 1) / nchunk;
     if (jchunk < 8) jchunk = Bc < 8 ? Bc : 8;
     if (jchunk > SMAXJ) jchunk = SMAXJ;
     nchunk = (Bc + jchunk - 1) / jchunk;
     a.jchunk = jchunk;
-    static bool lds_set = false;
-    if (!lds_set) {
-        if (hipFuncSetAttribute((const void*)filip_sim_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C::S_TOTAL) != hipSuccess)
-            return pclip_fail(PCLIP_ELAUNCH, "filip_sim_stream_kernel: cannot raise the dynamic LDS limit");
-        lds_set = true;
-    }
+    static PclipLdsLimit lds_limit;
+    if (int rc = pclip_ensure_lds(lds_limit, (const void*)filip_sim_stream_kernel, C::S_TOTAL, "filip_sim_stream_kernel")) return rc;
     hipLaunchKernelGGL(filip_sim_stream_kernel, dim3(a.ngroups * nchunk), dim3(C::NW * 64), C::S_TOTAL, (hipStream_t)stream, a);
     return pclip_check_launch("filip_sim_stream_kernel");
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <mutex>
 #include "../../include/pclip.h"
 
 #ifndef FLT_MAX
@@ -34,6 +35,27 @@ inline int pclip_check_launch(const char* what) {
 
 inline size_t pclip_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Dynamic-LDS launch limit of one kernel.  The attribute belongs to the (kernel, device) pair, so
+// what has been raised is remembered per device; the lock makes concurrent host threads safe.
+// Nothing here influences a result: it only decides whether hipFuncSetAttribute is called again.
+#define PCLIP_MAX_DEVICES 64
+struct PclipLdsLimit {
+    std::mutex mu;
+    int raised[PCLIP_MAX_DEVICES] = {};
+};
+inline int pclip_ensure_lds(PclipLdsLimit& lim, const void* fn, size_t bytes, const char* who) {
+    if (bytes <= 48 * 1024) return PCLIP_OK;   // within the default limit of every kernel
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return pclip_fail(PCLIP_EDEVICE, "%s: no current device", who);
+    std::lock_guard<std::mutex> lock(lim.mu);
+    const bool known = dev >= 0 && dev < PCLIP_MAX_DEVICES;
+    if (known && lim.raised[dev] >= (int)bytes) return PCLIP_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return pclip_fail(PCLIP_ELAUNCH, "%s: cannot raise the dynamic LDS limit to %zu bytes", who, bytes);
+    if (known) lim.raised[dev] = (int)bytes;
+    return PCLIP_OK;
+}
+
 // ---- device side -----------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -61,12 +83,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// internal launcher of the unit-norm FILIP score kernel (filip_fast.hip)
-int filip_sim_unit_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
-                          int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, void* stream);
-// internal launcher of the streaming unit-norm FILIP score kernel (filip_stream.hip)
+// internal launcher of the streaming unit-norm FILIP score kernel (filip_stream.hip); wgs_target:
+// workgroups to aim at per launch (<= 0: the default)
 int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
-                            int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, void* stream);
+                            int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int wgs_target,
+                            void* stream);
 // internal launcher of the general FILIP score kernel for long sequences (filip_long.hip)
 int filip_sim_long_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
                           int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, void* stream);

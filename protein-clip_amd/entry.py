@@ -64,6 +64,7 @@ def load_trunk(args, device):
             tokenizer = trunk = None
     is_synth = trunk is None
     if is_synth:
+        seed_mod.set_seed()   # every rank of a job builds the same random trunk
         tokenizer = synthetic.make_tokenizer()
         trunk = synthetic.make_esm(640, args.trunk_layers, 20)
     trunk = trunk.to(device)
@@ -92,8 +93,13 @@ def run(args, build_model, train_epoch, evaluate, loaders, device, rank):
     """The epoch loop of the reference's scripts: CSV of losses, best-validation checkpoint,
     reload of the best state for the test loss.  Returns (train_losses, val_losses, test_loss)."""
     seed_mod.set_seed()
+    distributed = dist.is_available() and dist.is_initialized()
     timestamp = datetime.now().strftime("%Y%m%d_%H%M%S_%f")
     base_path = f"{os.getcwd()}/runs/{timestamp}"
+    if distributed:   # one run directory for the job: rank 0's
+        shared = [base_path]
+        dist.broadcast_object_list(shared, src=0)
+        base_path = shared[0]
     if rank == 0:
         os.makedirs(base_path, exist_ok=True)
         print(f"All run info will be saved to {base_path}")
@@ -125,12 +131,18 @@ def run(args, build_model, train_epoch, evaluate, loaders, device, rank):
         print(f"Epoch {epoch + 1}/{args.epochs} - Train Loss: {train_loss:.4f}, Val Loss: {val_loss:.4f}")
     if log:
         log.close()
+    # Test loss of the best state.  The loss operators issue collectives on the whole job, so every
+    # rank takes part: all of them load rank 0's checkpoint (written before the barrier) and
+    # evaluate their own share of the test pairs; the value is the same on every rank.
+    if distributed:
+        dist.barrier()
     test_loss = None
-    if rank == 0:
+    if os.path.exists(model_save_path):
         best = build_model().to(device)
-        best.load_state_dict(torch.load(model_save_path, weights_only=True))
+        best.load_state_dict(torch.load(model_save_path, weights_only=True, map_location=device))
         test_loss = evaluate(best, test_loader)
-        print(f"Test Loss: {test_loss:.4f}")
-    if dist.is_available() and dist.is_initialized():
+        if rank == 0:
+            print(f"Test Loss: {test_loss:.4f}")
+    if distributed:
         dist.barrier()
     return train_losses, val_losses, test_loss

@@ -15,10 +15,16 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    """A per-device scratch buffer that only ever grows (reused across calls on a stream)."""
-    key = (device.type, device.index)
+    """Scratch for one call: one buffer per (device, stream) that only ever grows.  Calls on one
+    stream run in order, so they can share it; calls on different streams get different buffers.
+    A buffer that is outgrown may still be in use by kernels already enqueued on its stream: the
+    caching allocator is told so (``record_stream``) before the reference is dropped."""
+    stream = torch.cuda.current_stream(device)
+    key = (device.index, stream.cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            buf.record_stream(stream)
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
@@ -243,7 +249,9 @@ def filip_prep(h, mask, normalise: bool, tsign=None):
     return hn, mw
 
 
-def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True, unit_norm: bool = False):
+def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True, unit_norm: bool = False, stream_wgs: int = 0):
+    """``stream_wgs`` (tests, tuning): number of workgroups the unit-norm kernel aims at per launch
+    (0 = the library's default); the results do not depend on it."""
     dev = hnA.device
     Br, Bc = hnA.shape[0], hnB.shape[0]
     tt = _scalar(t, dev, "t")
@@ -251,7 +259,8 @@ def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True
     simB = torch.empty(Br, Bc, dtype=F32, device=dev)
     argA = torch.empty(Br, Bc, _tp(TA), dtype=torch.int16, device=dev) if want_arg else None
     argB = torch.empty(Br, Bc, _tp(TB), dtype=torch.int16, device=dev) if want_arg else None
-    check(_lib.load().pclip_filip_sim_fwd(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), int(unit_norm), ptr(simA),
+    check(_lib.load().pclip_filip_sim_fwd(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt),
+                                          (max(int(stream_wgs), 2) if stream_wgs else 1) if unit_norm else 0, ptr(simA),
                                           ptr(simB), ptr(argA), ptr(argB), stream_of(hnA)), "pclip_filip_sim_fwd")
     return simA, simB, argA, argB
 

@@ -56,13 +56,22 @@ def _process_batch(model, batch_data, tokenizer, device, compute_grad=False):
     return loss.item()
 
 
+def _distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def train(model, data_loader, optimizer, tokenizer, device):
-    """One epoch, one optimizer step per batch; returns the mean batch loss."""
+    """One epoch, one optimizer step per batch; returns the mean batch loss.  Under
+    ``torch.distributed`` the loss of a batch spans the batches of all ranks (all-gather inside
+    the loss) and every rank back-propagates its own rows, so the head gradients are summed over
+    the ranks before the step."""
     model.train()
     running = 0.0
     for batch in data_loader:
         optimizer.zero_grad()
         running += _process_batch(model, batch, tokenizer, device, compute_grad=True)
+        if _distributed():
+            _sum_head_grads(model)
         optimizer.step()
     return running / len(data_loader)
 
@@ -132,7 +141,7 @@ def train_gc(model, data_loader, tokenizer, optimizer, scaler, device, accumulat
     form one contrastive batch and one optimizer step.  Trailing sub-batches that do not fill
     a batch are encoded and dropped, as in the reference.  Returns the mean big-batch loss."""
     model.train()
-    distributed = dist.is_available() and dist.is_initialized()
+    distributed = _distributed()
     total, big_batches = 0.0, 0
     pending = []
     for step, (xx, yy) in enumerate(data_loader):

@@ -5,11 +5,16 @@ from __future__ import annotations
 import torch
 
 from .. import ops
+from .training_utils import _distributed, _sum_head_grads
 
 
 def _contrastive_loss(logits: torch.Tensor, use_dcl: bool = False) -> torch.Tensor:
     """``mean_i(-log E_ii + log sum_j E_ij)``, ``E = exp(logits)``; ``use_dcl`` removes the
-    diagonal from the denominator (training_utils_filip.py:4-23)."""
+    diagonal from the denominator (training_utils_filip.py:4-23).
+
+    Under ``torch.distributed`` ``ExtendedFILIP.forward`` returns this rank's rows against the B
+    sequences of all ranks, ``[B, W*B]``: the operator recognises that shape, takes column
+    ``rank*B + i`` as the target of row i and returns the mean over the global batch."""
     return ops.row_ce(logits, use_dcl=use_dcl)
 
 
@@ -33,12 +38,16 @@ def _process_batch(model, batch_data, tokenizer, device, compute_grad=False):
 
 def train(model, data_loader, optimizer, tokenier, device):
     """One epoch, one optimizer step per batch; returns the mean batch loss.  (The fourth
-    parameter keeps the reference's spelling so keyword calls stay valid.)"""
+    parameter keeps the reference's spelling so keyword calls stay valid.)  Under
+    ``torch.distributed`` every rank back-propagates the global loss through its own rows, so the
+    head and temperature gradients are summed over the ranks before the step."""
     model.train()
     running = 0.0
     for batch in data_loader:
         optimizer.zero_grad()
         running += _process_batch(model, batch, tokenier, device, compute_grad=True)
+        if _distributed():
+            _sum_head_grads(model)
         optimizer.step()
     return running / len(data_loader)
 

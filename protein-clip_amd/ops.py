@@ -165,9 +165,10 @@ class _RowCE(torch.autograd.Function):
     def forward(ctx, logits, use_dcl, row_offset, Bg, group, K):
         logits = logits.contiguous()
         lse, loss = K.rowce_fwd(logits, row_offset, Bg, use_dcl)
-        world, _ = _world(group)
-        if _collective(world):
-            dist.all_reduce(loss, group=group)
+        if group is not False:   # False: a whole matrix on this rank, nothing to sum over ranks
+            world, _ = _world(group)
+            if _collective(world):
+                dist.all_reduce(loss, group=group)
         ctx.K, ctx.cfg = K, (use_dcl, row_offset, Bg)
         ctx.save_for_backward(logits, lse)
         return loss.reshape(())
@@ -179,14 +180,36 @@ class _RowCE(torch.autograd.Function):
         return ctx.K.rowce_bwd(logits, lse, row_offset, Bg, use_dcl, g=g.reshape(1)), None, None, None, None, None
 
 
-def row_ce(logits: torch.Tensor, use_dcl: bool = False, row_offset: int = 0, global_batch: Optional[int] = None, group=None,
+def _row_shard(logits: torch.Tensor, group):
+    """(row_offset, global_batch) of a ``[Bl, W*Bl]`` block of scores under a process group of W > 1
+    ranks: what :func:`filip_similarity` returns there (this rank's A rows against the gathered B
+    sequences), so the target of local row i is column ``rank*Bl + i`` and the mean runs over the
+    ``W*Bl`` rows of all ranks.  Any other shape is a complete matrix of its own: (0, rows)."""
+    world, rank = _world(group)
+    Bl, Bc = logits.shape
+    if world > 1 and Bc == world * Bl:
+        return rank * Bl, Bc, True
+    return 0, Bl, False
+
+
+def row_ce(logits: torch.Tensor, use_dcl: bool = False, row_offset: Optional[int] = None, global_batch: Optional[int] = None, group=None,
            kernels=None) -> torch.Tensor:
     """``mean_i(-log E_ii + log sum_j E_ij)`` over the global batch; ``logits`` holds this rank's
-    rows, whose targets sit at column ``i + row_offset``."""
+    rows, whose targets sit at column ``i + row_offset``.
+
+    Without explicit ``row_offset`` / ``global_batch`` they follow from the shape: a ``[Bl, W*Bl]``
+    block under an initialised process group of W ranks is this rank's row block of the global
+    matrix (the loss is then summed over the ranks, every rank returns the global value and
+    back-propagates its own rows); anything else is a whole matrix with the diagonal as target."""
     if logits.dim() != 2:
         raise ValueError("row_ce: expected a 2-d logits tensor")
-    Bg = logits.shape[0] if global_batch is None else global_batch
-    return _RowCE.apply(_f32(logits), bool(use_dcl), row_offset, Bg, group, kernels or _hip_kernels)
+    if row_offset is None and global_batch is None:
+        row_offset, Bg, sharded = _row_shard(logits, group)
+    else:
+        row_offset = 0 if row_offset is None else row_offset
+        Bg = logits.shape[0] if global_batch is None else global_batch
+        sharded = Bg != logits.shape[0]
+    return _RowCE.apply(_f32(logits), bool(use_dcl), row_offset, Bg, group if (sharded or FORCE_COLLECTIVES) else False, kernels or _hip_kernels)
 
 
 # --------------------------------------------------------------------------------------
@@ -245,5 +268,15 @@ def filip_similarity(hA, hB, maskA, maskB, temperature, normalise: bool = False,
     if tuple(maskA.shape) != tuple(hA.shape[:2]) or tuple(maskB.shape) != tuple(hB.shape[:2]):
         raise ValueError("filip_similarity: masks must be [B,T] matching the embeddings")
     t = temperature if isinstance(temperature, torch.Tensor) else torch.tensor(float(temperature), device=hA.device)
+    world, _ = _world(group)
+    if world > 1:
+        # the B sequences of all ranks are gathered into one tensor: ranks whose batches were padded
+        # to different lengths first agree on the longest (padding tokens are masked out)
+        longest = torch.tensor([hB.shape[1]], dtype=torch.int64, device=hB.device)
+        dist.all_reduce(longest, op=dist.ReduceOp.MAX, group=group)
+        extra = int(longest.item()) - hB.shape[1]
+        if extra > 0:
+            hB = torch.nn.functional.pad(hB, (0, 0, 0, extra))
+            maskB = torch.nn.functional.pad(maskB, (0, extra))
     simA, simB, _, _ = _FilipSim.apply(_f32(hA), _f32(hB), maskA, maskB, _f32(t), bool(normalise), group, kernels or _hip_kernels)
     return simA, simB

@@ -16,6 +16,16 @@ def _l2(e, tval):
     return e / e.norm(dim=-1, keepdim=True).clamp_min(1e-12) * torch.exp(tval / 2)
 
 
+def masked_mean_fwd(h, mask):
+    m = mask.to(F32)
+    inv = 1.0 / m.sum(1).clamp(min=1.0)
+    return (h * m[..., None]).sum(1) * inv[:, None], inv, mask.to(torch.uint8)
+
+
+def masked_mean_bwd(g, m8, inv, T):
+    return m8.to(F32)[..., None] * (g * inv[:, None])[:, None, :]
+
+
 def l2norm_scale_fwd(e, t):
     return _l2(e, _s(t))
 
@@ -104,7 +114,7 @@ def filip_prep(h, mask, normalise, tsign=None):
     if tsign is not None and float(_s(tsign)) < 0:
         n = -n
     m = (mask != 0)
-    return _bf16(n) * m[..., None], m.to(torch.uint8)
+    return torch.where(m[..., None], _bf16(n), torch.zeros(())), m.to(torch.uint8)
 
 
 def _scores(hnA, mA, hnB, mB, t):
@@ -122,7 +132,7 @@ def _scores(hnA, mA, hnB, mB, t):
     return simA, simB, aA, aB
 
 
-def filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, want_arg=True, unit_norm=False):
+def filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, want_arg=True, unit_norm=False, stream_wgs=0):
     simA, simB, aA, aB = _scores(hnA, mwA, hnB, mwB, t)
     return simA, simB, aA.to(torch.int16), aB.to(torch.int16)
 
@@ -148,7 +158,7 @@ def filip_prep_bwd(h, dn, normalise, tsign=None, out=None):
         h_ = h.detach().clone().requires_grad_(True)
         with torch.enable_grad():
             ((h_ / h_.norm(dim=-1, keepdim=True)) * dn * sgn).sum().backward()
-        res = h_.grad
+        res = torch.nan_to_num(h_.grad)   # all-zero rows (length padding) carry no gradient
     else:
         res = dn * sgn
     if out is not None:

@@ -63,7 +63,10 @@ def _worker(rank, port, out_dir):
 @pytest.fixture(scope="module")
 def two_rank_results(tmp_path_factory):
     out_dir = str(tmp_path_factory.mktemp("gloo"))
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:   # a free port, picked by the kernel
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     mp.start_processes(_worker, args=(port, out_dir), nprocs=WORLD, join=True, start_method="spawn")
     return [torch.load(os.path.join(out_dir, f"rank{r}.pt"), weights_only=True) for r in range(WORLD)]
 

@@ -596,19 +596,13 @@ def test_filip_fused_backward_equals_the_two_calls(K, monkeypatch, window_kb):
 
 
 def test_filip_scores_do_not_depend_on_the_workgroup_count():
-    """The streaming kernel cuts the B side into chunks by a workgroup target (512 by default,
-    PCLIP_FILIP_STREAM_WGS, read once per process): scores and arg-max tables are bit-identical
-    for every cut (child processes, one per setting)."""
+    """The streaming kernel cuts the B side into chunks by a workgroup target (512 by default):
+    scores and arg-max tables are bit-identical for every cut."""
+    import importlib.util
     import os
-    import subprocess
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lines = []
-    for wgs in ("1", "40", "512", "5000"):
-        env = dict(os.environ, PCLIP_FILIP_STREAM_WGS=wgs)
-        res = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_wgs_check.py")], capture_output=True, text=True, timeout=200,
-                             cwd=root, env=env)
-        assert res.returncode == 0, res.stderr[-2000:]
-        lines.append([l for l in res.stdout.splitlines() if l.startswith("checksum")][-1])
-    assert len(set(lines)) == 1, lines
-
+    spec = importlib.util.spec_from_file_location("stream_wgs_check", os.path.join(root, "tools", "stream_wgs_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sums = [mod.checksum(w) for w in (2, 40, 0, 5000)]
+    assert len(set(sums)) == 1, sums

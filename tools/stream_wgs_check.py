@@ -1,6 +1,6 @@
-"""Prints a checksum of the FILIP scores and arg-max tables of one ragged problem; the
-workgroup target of the streaming kernel comes from PCLIP_FILIP_STREAM_WGS (read once per
-process), so a test runs this script once per setting and compares the lines."""
+"""Prints one checksum of the FILIP scores and arg-max tables of a ragged problem per workgroup
+target of the streaming kernel given on the command line (default: 2 40 512 5000); the lines
+must all be equal."""
 import hashlib
 import os
 import sys
@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from protein_clip_amd import kernels as K  # noqa: E402
 
 
-def main():
+def checksum(wgs):
     gen = torch.Generator().manual_seed(3)
     Br, Bc, TA, TB, d = 37, 83, 200, 256, 128
     dev = torch.device("cuda:0")
@@ -24,7 +24,7 @@ def main():
     t = torch.tensor([0.5], device=dev)
     hnA, mwA = K.filip_prep(hA, mA, True, tsign=t)
     hnB, mwB = K.filip_prep(hB, mB, True)
-    simA, simB, argA, argB = K.filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, want_arg=True, unit_norm=True)
+    simA, simB, argA, argB = K.filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, want_arg=True, unit_norm=True, stream_wgs=wgs)
     # arg entries of padding tokens are unspecified: zero them through the masks before hashing
     TAp, TBp = argA.shape[-1], argB.shape[-1]
     vA = torch.zeros(Br, TAp, dtype=torch.bool, device=dev)
@@ -37,8 +37,9 @@ def main():
     h = hashlib.sha256()
     for x in (simA, simB, argA, argB):
         h.update(x.cpu().numpy().tobytes())
-    print("checksum", h.hexdigest())
+    return h.hexdigest()
 
 
 if __name__ == "__main__":
-    main()
+    for wgs in [int(a) for a in sys.argv[1:]] or [2, 40, 512, 5000]:
+        print("checksum", wgs, checksum(wgs))

@@ -103,6 +103,19 @@ int pclip_clip_step(const float* e_pep, const float* e_rec, const float* t, int 
                     float* loss, float* de_pep, float* de_rec, float* dt,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* The same step without a workspace argument.  It has no counterpart in the reference: it exists
+ * for callers that cannot allocate device memory or size a workspace (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  The scratch of the step lives in
+ * a fixed device array inside the library (pclip_clip_step_noalloc_max_bytes() = 10 MiB per GPU,
+ * held until the process ends), which covers B <= 1024 at d = 128; larger problems are rejected
+ * with PCLIP_EINVAL.  No call allocates or frees.  The first call on a device looks the array's
+ * address up (once per device, with that device current).  All calls on one GPU share that GPU's
+ * array: calls that overlap in time on one GPU (two streams, two threads) race; calls on one stream
+ * are safe.  Results equal pclip_clip_step's. */
+size_t pclip_clip_step_noalloc_max_bytes(void);
+int pclip_clip_step_noalloc(const float* e_pep, const float* e_rec, const float* t, int B, int d,
+                            float* loss, float* de_pep, float* de_rec, float* dt, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Row-wise InfoNCE with the diagonal as target.
  * Replaces modules/training_utils_filip.py:15-23 (_contrastive_loss, incl. use_dcl).

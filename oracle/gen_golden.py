@@ -35,7 +35,18 @@ def _install_grad_cache_stand_in():
         return wrapped
 
     def cached(fn):
-        return fn
+        # what the package's decorator hands back for one tensor: the representation computed
+        # without a graph, as a leaf, and a closure that replays the forward for the backward
+        def wrapped(*args, **kw):
+            with torch.no_grad():
+                rep = fn(*args, **kw)
+            leaf = rep.detach().requires_grad_(True)
+
+            def replay(cached_rep):
+                again = fn(*args, **kw)
+                torch.autograd.backward(again, grad_tensors=cached_rep.grad)
+            return leaf, replay
+        return wrapped
 
     pkg = types.ModuleType("grad_cache")
     sub = types.ModuleType("grad_cache.functional")
@@ -217,6 +228,68 @@ def gen_loops(models, tu, tuf):
         json.dump(out, f, indent=1)
 
 
+def gen_ties(models, tuf):
+    """Exact ties: duplicated tokens on both sides (operands normalised and bf16-exact).  The
+    reference's ``amax`` backward splits a gradient evenly among tied maxima; a kernel that routes
+    it to ONE of the tied tokens agrees after summing over each group of identical tokens (and
+    everywhere for the other side, whose gradient is the same row whichever twin is picked)."""
+    FIL = models.ExtendedFILIP
+    B, TA, TB, d = 5, 40, 37, 128
+    g = torch.Generator().manual_seed(77)
+    hA = torch.randn(B, TA, d, generator=g)
+    hB = torch.randn(B, TB, d, generator=g)
+    groupA = torch.arange(TA); groupB = torch.arange(TB)
+    for a, b in [(3, 2), (9, 2), (33, 32)]:        # token a is a copy of token b (one triple, one across a 32-tile edge)
+        hA[:, a] = hA[:, b]; groupA[a] = b
+    for a, b in [(1, 0), (5, 4), (6, 4), (7, 4), (35, 20)]:
+        hB[:, a] = hB[:, b]; groupB[a] = b
+    lA = torch.randint(34, TA + 1, (B,), generator=g)
+    lB = torch.randint(36, TB + 1, (B,), generator=g)
+    mA = (torch.arange(TA)[None] < lA[:, None]).long()
+    mB = (torch.arange(TB)[None] < lB[:, None]).long()
+    nA = (hA / hA.norm(dim=-1, keepdim=True)).to(torch.bfloat16).float()
+    nB = (hB / hB.norm(dim=-1, keepdim=True)).to(torch.bfloat16).float()
+    a = nA.clone().requires_grad_(True); b = nB.clone().requires_grad_(True)
+    t = torch.tensor(0.8, requires_grad=True)
+    sA, sB = FIL._filip_similarity_score(a, b, mA, mB, t)
+    loss = tuf._compute_loss(sA, sB)
+    loss.backward()
+    np.savez_compressed(os.path.join(OUT, "filip_ties.npz"), hA=_np(nA), hB=_np(nB), maskA=_np(mA).astype(np.uint8),
+                        maskB=_np(mB).astype(np.uint8), t=np.float32(0.8), sim_A=_np(sA), sim_B=_np(sB), loss=_np(loss),
+                        d_hA=_np(a.grad), d_hB=_np(b.grad), d_t=_np(t.grad), groupA=_np(groupA), groupB=_np(groupB))
+
+
+def gen_topk(models, tu):
+    """``eval_gc_allrec_onepep`` of the reference (training_utils.py:174-228) on the tiny model of
+    the loop traces: for every peptide index k the list it returns (one rank: 1 + the number of
+    receptors of the first aggregated batch that score higher than receptor k)."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from protein_clip_amd import synthetic as S
+    from torch.utils.data import DataLoader
+    tok = S.make_tokenizer()
+    data = S.PairDataset(8, pep_len=(5, 12), rec_len=(10, 30), seed=7)
+    torch.manual_seed(42)
+    esm = S.make_esm(32, 2, 4)
+    model = models.ExtendedCLIP(32, 16, 2, 2, 0.0, esm)
+    loader = DataLoader(data, batch_size=4, shuffle=False, drop_last=True)
+    out = {"batch_size": 4, "agg_batches": 2, "seed": 42, "ranks": {}, "diag": {}}
+    for k in range(8):
+        out["ranks"][str(k)] = [int(v) for v in tu.eval_gc_allrec_onepep(model, loader, "cpu", tok, agg_batches=2, k=k)]
+    # the scores behind the ranks (peptide k against the eight receptors), to tell a near-tie from an error
+    with torch.no_grad():
+        rec = tok(data.rec, return_tensors="pt", padding=True)
+        rec["temperature"] = model.temperature
+        y = model.rec_encoder(rec)
+        for k in range(8):
+            pep = tok([data.pep[k]], return_tensors="pt", padding=True)
+            pep["temperature"] = model.temperature
+            x = model.pep_encoder(pep)
+            out["diag"][str(k)] = [float(v) for v in torch.exp(x @ y.t())[0]]
+    with open(os.path.join(OUT, "topk_trace.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.dont_write_bytecode = True
@@ -227,7 +300,14 @@ def main():
     import modules.models as models
     import modules.training_utils as tu
     import modules.training_utils_filip as tuf
+    if "--ties-topk-only" in sys.argv:
+        gen_ties(models, tuf)
+        gen_topk(models, tu)
+        print("tie and top-k fixtures written", flush=True)
+        return
     if "--loops-only" not in sys.argv:
+        gen_ties(models, tuf)
+        gen_topk(models, tu)
         gen_clip(tu)
         print("clip goldens written", flush=True)
         gen_filip(models, tuf)

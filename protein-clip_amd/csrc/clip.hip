@@ -328,10 +328,12 @@ extern "C" int pclip_clip_bwd(const float* X_own, const float* Y_own, const floa
 }
 
 // ---- fused one-GPU step ----------------------------------------------------------------
+// Workspace: x, y [B,d] | lse_row, lse_col [B] | the forward partials, later overwritten by the
+// gradient slabs (the partials are dead once clip_finalize_kernel has run).
 extern "C" size_t pclip_clip_step_workspace_bytes(int B, int d) {
     if (B < 1 || d < 1) return 0;
     return pclip_align_up((size_t)2 * B * d * sizeof(float), 256) + pclip_align_up((size_t)2 * B * sizeof(float), 256) +
-           pclip_clip_workspace_bytes(B, B, d) + clip_bwd_ws(B, d, 64);
+           pclip_clip_workspace_bytes(B, B, d);
 }
 
 extern "C" int pclip_clip_step(const float* e_pep, const float* e_rec, const float* t, int B, int d, float* loss, float* de_pep,
@@ -350,11 +352,52 @@ extern "C" int pclip_clip_step(const float* e_pep, const float* e_rec, const flo
     p += pclip_align_up((size_t)2 * B * sizeof(float), 256);
     void* cws = p;
     const size_t cws_bytes = pclip_clip_workspace_bytes(B, B, d);
-    float* slab = (float*)(p + cws_bytes);
+    float* slab = (float*)cws;
     if (int rc = l2norm_scale_fwd_pair_launch(e_pep, e_rec, t, x, y, B, d, dt, stream)) return rc;   // also clears dt
     if (int rc = pclip_clip_fwd(x, y, x, y, B, B, d, 0, lse_row, lse_col, loss, nullptr, 0, cws, cws_bytes, stream)) return rc;
     int ns = 1;
     if (int rc = clip_grad_launch(x, y, x, y, lse_row, lse_col, B, B, d, 0, nullptr, slab, &ns, st)) return rc;
     const size_t n = (size_t)B * d;
     return l2norm_scale_bwd_pair_launch(e_pep, e_rec, t, slab, slab + (size_t)ns * n, ns, n, de_pep, de_rec, dt, B, d, stream);
+}
+
+// ---- the same step for callers that cannot allocate --------------------------------------
+// The workspace of pclip_clip_step lives in a device array of this code object: every GPU the
+// library runs on holds its own copy at its own address until the process ends.  Host code never
+// uses the array's NAME as a pointer (that is a host-side stand-in, not a device address): the
+// address is asked for once per device, with that device current, and kept.
+#define CLIP_NOALLOC_SCRATCH_BYTES ((size_t)10 << 20)
+static __device__ __align__(256) unsigned char scratch[CLIP_NOALLOC_SCRATCH_BYTES];
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[PCLIP_MAX_DEVICES];   // device address of `scratch` on each device, once resolved
+
+static int clip_scratch_of_current_device(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PCLIP_MAX_DEVICES)
+        return pclip_fail(PCLIP_EDEVICE, "clip_step_noalloc: no current device (or more than %d devices)", PCLIP_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return pclip_fail(PCLIP_ELAUNCH, "clip_step_noalloc: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return PCLIP_OK;
+}
+
+extern "C" size_t pclip_clip_step_noalloc_max_bytes(void) { return CLIP_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int pclip_clip_step_noalloc(const float* e_pep, const float* e_rec, const float* t, int B, int d, float* loss, float* de_pep,
+                                       float* de_rec, float* dt, void* stream) {
+    PCLIP_REQUIRE(B >= 1 && d >= 1, "clip_step_noalloc: B=%d d=%d", B, d);
+    const size_t need = pclip_clip_step_workspace_bytes(B, d);
+    PCLIP_REQUIRE(need <= CLIP_NOALLOC_SCRATCH_BYTES,
+                  "clip_step_noalloc: B=%d d=%d needs %zu bytes of scratch, the built-in buffer holds %zu (B <= 1024 at d = 128); "
+                  "use pclip_clip_step with a caller-provided workspace", B, d, need, CLIP_NOALLOC_SCRATCH_BYTES);
+    void* ws = nullptr;
+    if (int rc = clip_scratch_of_current_device(&ws)) return rc;
+    // every buffer of the step inside the scratch is written before it is read (dt is cleared by the
+    // first kernel), so nothing has to be zeroed between calls
+    return pclip_clip_step(e_pep, e_rec, t, B, d, loss, de_pep, de_rec, dt, ws, CLIP_NOALLOC_SCRATCH_BYTES, stream);
 }

@@ -54,4 +54,6 @@ def test_bad_arguments_are_rejected_before_launch(lib):
     assert b"workspace" in lib.pclip_last_error()
     assert lib.pclip_filip_prep(one, one, 4, 5000, 128, 1, None, one, one, None) == -1                                # T > 4096
     assert lib.pclip_filip_prep(one, one, 4, 64, 129, 1, None, one, one, None) == -1                                  # d > 128
+    assert lib.pclip_clip_step_noalloc(one, one, one, 4096, 128, one, one, one, one, None) == -1                      # beyond the built-in scratch
+    assert b"built-in buffer" in lib.pclip_last_error()
     assert lib.pclip_rowce_fwd(one, 8, 4, 0, 8, 0, one, one, None) == -1                                              # target column out of range

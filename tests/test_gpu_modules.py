@@ -117,6 +117,21 @@ def test_filip_group_axis_variant(env, filip_cases):
     torch.testing.assert_close(grouped[1][0, 1], flat[1][0:3, 2:4])
 
 
+def test_topk_eval_matches_the_reference_ranks(env):
+    """``eval_gc_allrec_onepep`` (training_utils.py:174-228 of the reference) on the exp-logits
+    kernel: the rank list the reference returns for every peptide index k of the tiny model."""
+    with open(os.path.join(ROOT, "tests", "golden", "topk_trace.json")) as f:
+        want = json.load(f)
+    S = env["S"]
+    data = S.PairDataset(8, pep_len=(5, 12), rec_len=(10, 30), seed=7)
+    torch.manual_seed(want["seed"])
+    model = env["models"].ExtendedCLIP(32, 16, 2, 2, 0.0, S.make_esm(32, 2, 4)).cuda()
+    loader = DataLoader(data, batch_size=want["batch_size"], shuffle=False, drop_last=True)
+    for k in range(8):
+        got = env["tu"].eval_gc_allrec_onepep(model, loader, "cuda", env["tok"], agg_batches=want["agg_batches"], k=k)
+        assert got == want["ranks"][str(k)], (k, got, want["ranks"][str(k)], want["diag"][str(k)])
+
+
 def test_big_batch_trainer_equals_one_big_batch(env):
     """train_gc with 2 sub-batches of 4 must take the same optimizer step as one plain step on
     the 8 pairs at once (dropout off): same loss, same updated head weights."""

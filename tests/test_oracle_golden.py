@@ -100,3 +100,52 @@ def test_filip_benchmark_size_rows():
     close(sA, g["sim_A"][:8, :32], 1e-5, 1e-6)
     close(sB, g["sim_B"][:8, :32], 1e-5, 1e-6)
     close(O.filip_loss(g["sim_A"], g["sim_B"]), g["loss"], 1e-6, 1e-6)
+
+
+def test_filip_exact_ties_split_evenly_like_the_reference():
+    """Duplicated tokens (exact ties of the max): the oracle's gradient equals the reference's
+    even split among the tied tokens, element by element."""
+    c = load_flat("filip_ties.npz")
+    a = c["hA"].clone().requires_grad_(True)
+    b = c["hB"].clone().requires_grad_(True)
+    t = c["t"].clone().requires_grad_(True)
+    sA, sB = O.filip_similarity_block(a, b, c["maskA"], c["maskB"], t)
+    close(sA, c["sim_A"], 1e-6, 1e-7)
+    close(sB, c["sim_B"], 1e-6, 1e-7)
+    O.filip_loss(sA, sB).backward()
+    close(a.grad, c["d_hA"], 1e-5, 1e-9)
+    close(b.grad, c["d_hB"], 1e-5, 1e-9)
+    close(t.grad, c["d_t"], 1e-5, 1e-7)
+    # the fixture does contain ties: twins receive equal, nonzero shares
+    twins = (c["groupB"] != torch.arange(c["groupB"].numel())).nonzero().flatten()
+    assert len(twins) == 5
+    for tw in twins.tolist():
+        rep = int(c["groupB"][tw])
+        assert torch.equal(c["d_hB"][:, tw], c["d_hB"][:, rep]) and c["d_hB"][:, rep].abs().sum() > 0
+
+
+def test_topk_eval_host_logic_against_the_reference_ranks():
+    """``eval_gc_allrec_onepep`` (training_utils.py:174-228 of the reference) on the tiny model of
+    the loop traces, compute through the CPU stand-in provider: same rank list for every k."""
+    import json
+    import os
+    import cpu_provider as P
+    from torch.utils.data import DataLoader
+    from protein_clip_amd import ops, synthetic as S
+    from protein_clip_amd.modules import models, training_utils
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "topk_trace.json")) as f:
+        want = json.load(f)
+    tok = S.make_tokenizer()
+    data = S.PairDataset(8, pep_len=(5, 12), rec_len=(10, 30), seed=7)
+    torch.manual_seed(want["seed"])
+    model = models.ExtendedCLIP(32, 16, 2, 2, 0.0, S.make_esm(32, 2, 4))
+    loader = DataLoader(data, batch_size=want["batch_size"], shuffle=False, drop_last=True)
+    real = ops._hip_kernels
+    ops._hip_kernels = P
+    try:
+        for k in range(8):
+            got = training_utils.eval_gc_allrec_onepep(model, loader, "cpu", tok, agg_batches=want["agg_batches"], k=k)
+            assert got == want["ranks"][str(k)], (k, got, want["ranks"][str(k)], want["diag"][str(k)])
+    finally:
+        ops._hip_kernels = real

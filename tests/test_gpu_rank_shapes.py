@@ -81,10 +81,10 @@ def test_filip_rank_shape_256_by_2048(K):
     mAd, mBd = mA.cuda().bool(), mB.cuda().bool()
     for i in rows:
         sim = torch.einsum("ad,jbd->jab", nA[i], nB).masked_fill(~(mAd[i][None, :, None] & mBd[:, None, :]), float("-inf"))
-        pickA = torch.gather(sim, 2, argA[i, :, :L, None].long()).squeeze(2)
+        pickA = torch.gather(sim, 2, argA[i, :, :L, None].long().clamp(0, L - 1)).squeeze(2)   # entries of padding tokens are unspecified
         okA = mAd[i][None, :].expand_as(pickA)
         assert (sim.amax(2) - pickA)[okA].abs().max() <= 2e-6
-        pickB = torch.gather(sim, 1, argB[i, :, None, :L].long()).squeeze(1)
+        pickB = torch.gather(sim, 1, argB[i, :, None, :L].long().clamp(0, L - 1)).squeeze(1)
         assert (sim.amax(1) - pickB)[mBd].abs().max() <= 2e-6
     # backward given the routing: every token of both sides
     dnA, dnB, dt = K.filip_sim_bwd(hnA, mwA, L, hnB, mwB, L, t, simA, simB, argA, argB, gA.cuda(), gB.cuda())

@@ -1,6 +1,7 @@
 """The allocation-free CLIP step (pclip_clip_step_noalloc) against pclip_clip_step, through the C
-ABI: same loss and gradients, bit for bit, on two calls in a row, the second one smaller (the
-built-in scratch keeps the first call's contents), and a clear refusal beyond the built-in size."""
+ABI: same loss and embedding gradients bit for bit and the same temperature gradient to f32
+summation order (rtol 1e-5), on calls in a row of which the second is smaller than the first (the
+built-in scratch keeps the previous call's contents), and a clear refusal beyond the built-in size."""
 import ctypes
 
 import pytest
@@ -42,9 +43,11 @@ def test_noalloc_clip_step_equals_the_workspace_entry_point():
     assert lib.pclip_clip_step_noalloc_max_bytes() == 10 << 20
     for B, d, seed in [(256, 128, 1), (40, 64, 2), (1024, 128, 3), (7, 8, 4)]:   # large, then smaller, then the largest, then tiny
         (want, got), (e_pep, e_rec) = _run_both(lib, B, d, seed)
-        for a, b in zip(got, want):
+        for a, b in zip(got[:3], want[:3]):   # loss and both embedding gradients: the same kernels in the same order
             assert torch.isfinite(a).all()
             assert torch.equal(a, b), (B, d, (a - b).abs().max())
+        # dt is a sum of float atomic adds, whose order differs from launch to launch
+        torch.testing.assert_close(got[3], want[3], rtol=1e-5, atol=1e-7)
         ol, odp, _, odt = O.clip_step(e_pep, e_rec, torch.tensor(0.9))
         torch.testing.assert_close(got[0].reshape(()), ol, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(got[1], odp, rtol=1e-4, atol=2e-7)

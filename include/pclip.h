@@ -195,9 +195,8 @@ int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int
  * d loss / d (normalised operand) in the padded [.,Tp,128] layout of prep; dt is
  * ACCUMULATED: dt += -(1/t) * sum(gA*sim_A + gB*sim_B).  `ws` holds the bucketed token lists
  * (sized by pclip_filip_bwd_workspace_bytes; about 4*Br*Bc*(TAp+TBp) bytes, plus eight
- * partial copies of dnA and dnB when the operand images exceed the L2 window budget: 2 MB,
- * or PCLIP_FILIP_BWD_WINDOW_KB from the environment, which must not change between the
- * workspace query and the call).  The order in
+ * partial copies of dnA and dnB when the operand images exceed the L2 window budget of 2 MB).
+ * The order in
  * which a row's contributions are summed is not fixed, so results may differ in the last
  * bits from run to run.  Either of dnA, dnB may be NULL: that side is skipped (dt is produced
  * together with dnA), so a caller can run the B side first and start exchanging dnB between

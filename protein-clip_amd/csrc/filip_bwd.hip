@@ -17,7 +17,6 @@
 // adds to (later launches, for partner sets beyond eight windows) one of eight PARTIAL
 // gradients; a last pass sums the eight partials.
 #include "pclip_common.h"
-#include <stdlib.h>
 
 #define FD 128
 #define BWD_XCDS 8          // windows per gather launch = partial gradients
@@ -401,17 +400,11 @@ __global__ __launch_bounds__(256) void filip_window_sum_kernel(const float4* __r
 // ---- host side -------------------------------------------------------------------------
 static inline int tp32(int T) { return (T + 31) / 32 * 32; }
 
-// Window plan of one gather side.  One window when the partner images fit the budget (2 MB by
-// default: half an XCD's L2; PCLIP_FILIP_BWD_WINDOW_KB overrides it, for tests), else windows of
-// about that size in multiples of eight.
+// Window plan of one gather side.  One window when the partner images fit the budget (2 MB: half
+// an XCD's L2), else windows of about that size in multiples of eight.
 struct BwdPlan { int nwt, qpw; };
-static size_t bwd_window_bytes() {
-    const char* e = getenv("PCLIP_FILIP_BWD_WINDOW_KB");   // read on every call: a test may change it
-    const long kb = e ? atol(e) : 0;
-    return kb > 0 ? (size_t)kb << 10 : (size_t)2 << 20;
-}
 static BwdPlan bwd_plan(int Np, int TPp) {
-    const size_t per = (size_t)TPp * FD * 2, budget = bwd_window_bytes();
+    const size_t per = (size_t)TPp * FD * 2, budget = (size_t)2 << 20;
     BwdPlan pl;
     if ((size_t)Np * per <= budget || Np < BWD_XCDS) { pl.nwt = 1; pl.qpw = Np; return pl; }
     int qpw = (int)(budget / per);

@@ -332,36 +332,23 @@ def test_filip_backward_matches_oracle(K, filip_cases):
         close(dt, dt_ref.reshape(1), 1e-4, 1e-5)
 
 
-def test_filip_backward_partner_windows_equal_single_window(K, monkeypatch):
-    """The backward cuts the partner sequences into L2-sized windows (eight per gather launch,
-    later launches accumulating).  Forced here with a tiny window budget on a ragged batch whose
-    size is no multiple of eight and which holds an empty sequence; the result must equal the
-    single-window path up to summation order."""
+def test_filip_backward_partner_windows(K):
+    """The backward cuts the partner sequences into windows of 2 MB of images (eight per gather
+    launch, later launches accumulating) as soon as one side's images exceed that.  40 sequences of
+    up to 256 tokens are 2.6 MB a side: two windows with partners, six empty ones, a batch size that
+    is no multiple of eight, one empty sequence.  Routing and arithmetic as in every other case."""
     gen = torch.Generator().manual_seed(5)
-    B, TA, TB, d = 19, 40, 61, 128
+    B, TA, TB, d = 40, 250, 256, 128
     hA, hB = torch.randn(B, TA, d, generator=gen), torch.randn(B, TB, d, generator=gen)
     lA, lB = torch.randint(1, TA + 1, (B,), generator=gen), torch.randint(1, TB + 1, (B,), generator=gen)
     lB[3] = 0
     mA = (torch.arange(TA)[None] < lA[:, None]).to(torch.uint8)
     mB = (torch.arange(TB)[None] < lB[:, None]).to(torch.uint8)
-    t = torch.tensor(1.0)
     gA, gB = torch.randn(B, B, generator=gen), torch.randn(B, B, generator=gen)
-    hnA, mwA, hnB, mwB, simA, simB, argA, argB = _filip_fwd(K, hA, hB, mA, mB, t, normalise=True)
-    outs = []
-    for kb in (None, "16", "40"):
-        if kb is None:
-            monkeypatch.delenv("PCLIP_FILIP_BWD_WINDOW_KB", raising=False)
-        else:
-            monkeypatch.setenv("PCLIP_FILIP_BWD_WINDOW_KB", kb)
-        outs.append(K.filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, dev(t.reshape(1)), simA, simB, argA, argB, dev(gA), dev(gB)))
-    monkeypatch.delenv("PCLIP_FILIP_BWD_WINDOW_KB", raising=False)
-    for dnA, dnB, dt in outs[1:]:
-        close(dnA, outs[0][0].cpu(), 1e-5, 1e-6)
-        close(dnB, outs[0][1].cpu(), 1e-5, 1e-6)
-        # scores against the empty sequence are -inf (a sum of -FLT_MAX), which makes dt NaN in
-        # the reference as well: only require that both paths agree
-        torch.testing.assert_close(dt.cpu(), outs[0][2].cpu(), rtol=1e-6, atol=1e-6, equal_nan=True)
-    assert outs[0][0].abs().sum() > 0 and torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    gA[:, 3] = 0   # scores against the empty sequence are -inf / 0: keep them out of dt
+    gB[:, 3] = 0
+    res = _check_routing_and_backward(K, hA, hB, mA, mB, torch.tensor(1.0), True, gA, gB, "windows")
+    assert torch.isfinite(res[8]).all() and torch.isfinite(res[9]).all() and res[8].abs().sum() > 0
 
 
 def _check_routing_and_backward(K, hA, hB, mA, mB, t, normalise, gA, gB, tag=""):
@@ -639,17 +626,12 @@ def test_filip_random_small_shapes_against_oracle(K):
             assert torch.allclose(dt.cpu(), dt_ref.reshape(1), rtol=1e-4, atol=1e-5), tag
 
 
-@pytest.mark.parametrize("window_kb", [None, "16"])
-def test_filip_fused_backward_equals_the_two_calls(K, monkeypatch, window_kb):
+@pytest.mark.parametrize("Br,Bc,TA,TB", [(11, 13, 37, 70), (40, 36, 256, 250)])
+def test_filip_fused_backward_equals_the_two_calls(K, Br, Bc, TA, TB):
     """pclip_filip_bwd_fused (score backward + prep backward, partials summed inside the latter)
     against pclip_filip_sim_bwd followed by pclip_filip_prep_bwd, single window and windowed."""
-    if window_kb is None:
-        monkeypatch.delenv("PCLIP_FILIP_BWD_WINDOW_KB", raising=False)
-    else:
-        monkeypatch.setenv("PCLIP_FILIP_BWD_WINDOW_KB", window_kb)
     gen = torch.Generator().manual_seed(31)
     for normalise, d, tval in [(True, 128, 0.9), (False, 20, -1.1)]:
-        Br, Bc, TA, TB = 11, 13, 37, 70
         hA, hB = torch.randn(Br, TA, d, generator=gen), torch.randn(Bc, TB, d, generator=gen)
         mA = (torch.rand(Br, TA, generator=gen) > 0.3).to(torch.uint8)
         mB = (torch.rand(Bc, TB, generator=gen) > 0.3).to(torch.uint8)
@@ -666,7 +648,6 @@ def test_filip_fused_backward_equals_the_two_calls(K, monkeypatch, window_kb):
         got = K.filip_bwd_fused(hnA, mwA, hnB, mwB, t, simA, simB, argA, argB, gA, gB, hAd, hBd, normalise)
         for a, b in zip(got, want):
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
-    monkeypatch.delenv("PCLIP_FILIP_BWD_WINDOW_KB", raising=False)
 
 
 def test_filip_scores_do_not_depend_on_the_workgroup_count():

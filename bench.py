@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--full-length", action="store_true",
                     help="also time the score kernel alone with every token valid (secondary record; off by default so that a "
                          "profiler trace of the default command holds launches of the benchmark shape only)")
+    ap.add_argument("--no-rank-shapes", action="store_true",
+                    help="skip the secondary records that time, on this one GPU, the kernels one rank of the two 8-GPU "
+                         "configurations runs (CLIP 1024 x 8192, FILIP 256 x 2048; never part of `value`)")
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="one GPU, but through the multi-rank code: a one-rank RCCL group, the sharded steps with every "
                          "collective issued, the per-rank shapes of an N>1 run (not a benchmark result)")
@@ -99,6 +102,72 @@ def cpu_baseline(cpu, clip_b, filip_b):
     }
 
 
+def _median_ms(fn, reps):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    fn()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return statistics.median(a.elapsed_time(b) for a, b in ev)
+
+
+def rank_shape_records(K, device):
+    """One rank's kernels of the two 8-GPU configurations, timed on this GPU with the gathered
+    batch formed locally (no collectives): what the all-gather would deliver, then exactly the
+    launches a rank issues."""
+    out = {}
+    g = torch.Generator().manual_seed(88)
+    t = torch.tensor([1.0], device=device)
+    # CLIP: 1024 own rows of a global batch of 8192
+    Br, Bg = 1024, 8192
+    x_all = torch.nn.functional.normalize(torch.randn(Bg, D, generator=g)).to(device) * 1.6487
+    y_all = torch.nn.functional.normalize(torch.randn(Bg, D, generator=g)).to(device) * 1.6487
+    off = 3072
+    x, y = x_all[off:off + Br].contiguous(), y_all[off:off + Br].contiguous()
+    res = {}
+
+    def cf():
+        res["r"] = K.clip_fwd(x, y, x_all, y_all, off)
+    ms_f = _median_ms(cf, 20)
+    lr, lc = res["r"][0].repeat(Bg // Br), res["r"][1].repeat(Bg // Br)   # stand-ins for the gathered vectors
+    ms_b = _median_ms(lambda: K.clip_bwd(x, y, x_all, y_all, lr, lc, off), 20)
+    flop = 6.0 * Br * Bg * D
+    out["rank_shape_clip_1024x8192"] = {
+        "note": "one rank of CLIP on 8 GPUs (global batch 8192), kernels only, timed on one GPU; not part of `value`",
+        "fwd_ms": ms_f, "bwd_ms": ms_b, "algorithmic_flops": flop,
+        "f32_mfma_TFLOPs": flop / ((ms_f + ms_b) * 1e-3) / 1e12,
+        "f32_mfma_frac": flop / ((ms_f + ms_b) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+    }
+    # FILIP: 256 own A sequences against 2048 gathered B sequences
+    Bl, Bq = 256, 2048
+    hA = torch.randn(Bl, L, D, generator=g).to(device)
+    hB = torch.randn(Bq, L, D, generator=g).to(device)
+    lA = torch.randint(128, L + 1, (Bl, 1), generator=g)
+    lB = torch.randint(128, L + 1, (Bq, 1), generator=g)
+    mA = (torch.arange(L)[None] < lA).to(torch.uint8).to(device)
+    mB = (torch.arange(L)[None] < lB).to(torch.uint8).to(device)
+    hnA, mwA = K.filip_prep(hA, mA, True, tsign=t)
+    hnB, mwB = K.filip_prep(hB, mB, True)
+    keep = {}
+
+    def ff():
+        keep["f"] = K.filip_sim_fwd(hnA, mwA, L, hnB, mwB, L, t, want_arg=True, unit_norm=True)
+    ms_s = _median_ms(ff, 5)
+    simA, simB, argA, argB = keep["f"]
+    gA = torch.randn(Bl, Bq, device=device) / Bq
+    gB = torch.randn(Bl, Bq, device=device) / Bq
+    ms_bw = _median_ms(lambda: K.filip_sim_bwd(hnA, mwA, L, hnB, mwB, L, t, simA, simB, argA, argB, gA, gB), 5)
+    fl = 2.0 * D * float(lA.sum()) * float(lB.sum())
+    out["rank_shape_filip_256x2048"] = {
+        "note": "one rank of FILIP on 8 GPUs (global batch 2048), kernels only, timed on one GPU; not part of `value`",
+        "scores_ms": ms_s, "backward_ms": ms_bw, "algorithmic_flops_scores": fl,
+        "sim_kernel_TFLOPs": fl / (ms_s * 1e-3) / 1e12, "sim_kernel_mfma_frac": fl / (ms_s * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+    }
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,9 +204,12 @@ def main():
     cpu, dv = make_inputs(rank, clip_bl, filip_bl, device)
     t = torch.tensor([1.0], device=device)
 
+    # one GPU: the pre-allocated steps (every buffer created once, a step only enqueues kernels);
+    # several ranks: the sharded steps with their collectives
     clip_fused = None if multi else K.ClipStep(clip_bl, D, device)
     clip_sh = ClipShardedStep() if multi else None
-    filip_sh = FilipShardedStep()
+    filip_fused = None if multi else K.FilipStep(filip_bl, filip_bl, L, L, D, device)
+    filip_sh = FilipShardedStep() if multi else None
 
     def clip_step():
         if clip_fused is not None:
@@ -145,6 +217,8 @@ def main():
         return clip_sh.run(dv["e_pep"], dv["e_rec"], t)
 
     def filip_step(ev=None):
+        if filip_fused is not None:
+            return filip_fused.run(dv["hA"], dv["hB"], dv["mA"], dv["mB"], t, sim_events=ev)
         return filip_sh.run(dv["hA"], dv["hB"], dv["mA"], dv["mB"], t, sim_events=ev)
 
     def bracket(fn, steps):
@@ -260,6 +334,8 @@ def main():
                     "sim_kernel_ms": full_ms, "sim_kernel_TFLOPs": ff / (full_ms * 1e-3) / 1e12,
                     "sim_kernel_mfma_frac": ff / (full_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                 }
+        if not multi and not args.no_rank_shapes and args.workload == "both":
+            workloads.update(rank_shape_records(K, device))
         out = {
             "metric": "protein_pairs_per_sec", "value": pairs / (total / args.steps), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": SETTLE_STEPS, "ms_per_step": total / args.steps * 1e3,

@@ -328,10 +328,13 @@ extern "C" int pclip_clip_bwd(const float* X_own, const float* Y_own, const floa
 }
 
 // ---- fused one-GPU step ----------------------------------------------------------------
-// Workspace: x, y [B,d] | lse_row, lse_col [B] | the forward partials, later overwritten by the
-// gradient slabs (the partials are dead once clip_finalize_kernel has run).
+// B <= 512: one persistent launch (clip_step.hip).  Larger batches: normalise, scores, gradients,
+// normalise backward as separate launches; workspace: x, y [B,d] | lse_row, lse_col [B] | the
+// forward partials, later overwritten by the gradient slabs (the partials are dead once
+// clip_finalize_kernel has run).
 extern "C" size_t pclip_clip_step_workspace_bytes(int B, int d) {
     if (B < 1 || d < 1) return 0;
+    if (clip_step_fused_ok(B, d)) return clip_step_fused_ws_bytes(B, d);   // one persistent launch
     return pclip_align_up((size_t)2 * B * d * sizeof(float), 256) + pclip_align_up((size_t)2 * B * sizeof(float), 256) +
            pclip_clip_workspace_bytes(B, B, d);
 }
@@ -342,6 +345,9 @@ extern "C" int pclip_clip_step(const float* e_pep, const float* e_rec, const flo
     if (int rc = clip_check("clip_step", B, B, d, 0)) return rc;
     PCLIP_REQUIRE(ws_bytes >= pclip_clip_step_workspace_bytes(B, d), "clip_step: workspace %zu < %zu bytes", ws_bytes,
                   pclip_clip_step_workspace_bytes(B, d));
+    PCLIP_REQUIRE(((uintptr_t)e_pep | (uintptr_t)e_rec | (uintptr_t)de_pep | (uintptr_t)de_rec | (uintptr_t)ws) % 16 == 0,
+                  "clip_step: pointers must be 16-byte aligned");
+    if (clip_step_fused_ok(B, d)) return clip_step_fused_launch(e_pep, e_rec, t, B, d, loss, de_pep, de_rec, dt, ws, stream);
     hipStream_t st = (hipStream_t)stream;
     char* p = (char*)ws;
     float* x = (float*)p;
@@ -398,6 +404,7 @@ extern "C" int pclip_clip_step_noalloc(const float* e_pep, const float* e_rec, c
     void* ws = nullptr;
     if (int rc = clip_scratch_of_current_device(&ws)) return rc;
     // every buffer of the step inside the scratch is written before it is read (dt is cleared by the
-    // first kernel), so nothing has to be zeroed between calls
+    // first kernel, the barrier counter of the one-launch form by a memset node in front of it), so
+    // nothing else has to be zeroed between calls
     return pclip_clip_step(e_pep, e_rec, t, B, d, loss, de_pep, de_rec, dt, ws, CLIP_NOALLOC_SCRATCH_BYTES, stream);
 }

@@ -99,3 +99,9 @@ int l2norm_scale_bwd_pair_launch(const float* e0, const float* e1, const float* 
 // internal launcher of the prep backward over a sum of gradient slabs (filip.hip)
 int filip_prep_bwd_launch(const float* h, const float* dn, int nslab, size_t slab_stride, size_t row_stride, const uint32_t* mw, int B, int T, int d,
                           int normalise, const float* tsign, int accumulate, float* dh, void* stream);
+
+// ---- the one-launch CLIP step for B <= 512 (clip_step.hip) ----
+bool clip_step_fused_ok(int B, int d);
+size_t clip_step_fused_ws_bytes(int B, int d);
+int clip_step_fused_launch(const float* e_pep, const float* e_rec, const float* t, int B, int d, float* loss, float* de_pep, float* de_rec,
+                           float* dt, void* ws, void* stream);

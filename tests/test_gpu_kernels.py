@@ -327,8 +327,9 @@ def test_filip_backward_matches_oracle(K, filip_cases):
                                        dev(gA), dev(gB))
         dA = K.filip_prep_bwd(dev(hA), dnA, normalise=not pre, tsign=dev(t.reshape(1)))
         dB = K.filip_prep_bwd(dev(hB), dnB, normalise=not pre)
-        mostly_close(dA, dA_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)
-        mostly_close(dB, dB_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)
+        # measured on MI355X (tools/measure_bwd_outliers.py): no element outside, relative L2 error 1e-7..2e-7
+        mostly_close(dA, dA_ref, 1e-3, 1e-6, max_bad_frac=0.0, max_rel_l2=1e-5)
+        mostly_close(dB, dB_ref, 1e-3, 1e-6, max_bad_frac=0.0, max_rel_l2=1e-5)
         close(dt, dt_ref.reshape(1), 1e-4, 1e-5)
 
 
@@ -507,10 +508,10 @@ def test_filip_benchmark_size_backward_rows_against_oracle(K):
         sA, sB, da, _, _ = _oracle_filip_grads(hA[i:i + 1], hB, mA[i:i + 1], mB, tt, True, gA[i:i + 1], gB[i:i + 1])
         close(simA[i:i + 1], sA, 3e-5, 3e-5)   # 1/t = 14 scales the 2e-6 of the unit-temperature scores
         close(simB[i:i + 1], sB, 3e-5, 3e-5)
-        mostly_close(dA[i:i + 1], da, 1e-3, 1e-7, max_bad_frac=0.06, max_rel_l2=0.02)
+        mostly_close(dA[i:i + 1], da, 1e-3, 1e-7, max_bad_frac=0.03, max_rel_l2=0.02)   # measured: <= 0.03 %, 1e-4
     for j in (0, 131):   # every A sequence against B sequence j
         _, _, _, db, _ = _oracle_filip_grads(hA, hB[j:j + 1], mA, mB[j:j + 1], tt, True, gA[:, j:j + 1], gB[:, j:j + 1])
-        mostly_close(dB[j:j + 1], db, 1e-3, 1e-7, max_bad_frac=0.06, max_rel_l2=0.02)
+        mostly_close(dB[j:j + 1], db, 1e-3, 1e-7, max_bad_frac=0.03, max_rel_l2=0.02)   # measured: <= 1.2 %, 8e-3
     for h, dh, m in ((hA, dA, mA), (hB, dB, mB)):
         assert (dh[~m.bool()] == 0).all()
         dots = (dh * h).sum(-1)[m.bool()]
@@ -573,8 +574,8 @@ def test_filip_sequences_beyond_one_lds_image(K, TA, TB, normalise):
     dnA, dnB, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, dev(t.reshape(1)), simA, simB, argA, argB, dev(gA), dev(gB))
     dA = K.filip_prep_bwd(dev(hA), dnA, normalise=normalise, tsign=dev(t.reshape(1)))
     dB = K.filip_prep_bwd(dev(hB), dnB, normalise=normalise)
-    mostly_close(dA, dA_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)
-    mostly_close(dB, dB_ref, 1e-3, 1e-6, max_bad_frac=0.01, max_rel_l2=0.05)
+    mostly_close(dA, dA_ref, 1e-3, 1e-6, max_bad_frac=0.005, max_rel_l2=0.01)
+    mostly_close(dB, dB_ref, 1e-3, 1e-6, max_bad_frac=0.005, max_rel_l2=0.01)
     close(dt, dt_ref.reshape(1), 1e-4, 1e-5)
 
 
@@ -618,8 +619,8 @@ def test_filip_random_small_shapes_against_oracle(K):
         dA = K.filip_prep_bwd(dev(hA), dnA, normalise=normalise, tsign=dev(t.reshape(1)))
         dB = K.filip_prep_bwd(dev(hB), dnB, normalise=normalise)
         try:
-            mostly_close(dA, dA_ref, 1e-3, 1e-6, max_bad_frac=0.02, max_rel_l2=0.05)
-            mostly_close(dB, dB_ref, 1e-3, 1e-6, max_bad_frac=0.02, max_rel_l2=0.05)
+            mostly_close(dA, dA_ref, 1e-3, 1e-6, max_bad_frac=0.005, max_rel_l2=0.01)
+            mostly_close(dB, dB_ref, 1e-3, 1e-6, max_bad_frac=0.005, max_rel_l2=0.01)
         except AssertionError as exc:
             raise AssertionError(f"{tag}: {exc}") from None
         if bool(ok.all()):

@@ -98,8 +98,8 @@ def test_filip_score_function_and_loss_autograd(env, filip_cases):
         torch.testing.assert_close(t.grad.cpu(), c["d_t"], rtol=1e-4, atol=1e-6)
         for got, want in ((a.grad.cpu(), c["d_hA"]), (b.grad.cpu(), c["d_hB"])):
             bad = ((got - want).abs() > 1e-6 + 1e-3 * want.abs()).float().mean().item()
-            assert bad <= 0.01
-            assert ((got - want).norm() / want.norm()).item() < 0.05
+            assert bad == 0.0   # measured: none outside, relative L2 error 1e-7
+            assert ((got - want).norm() / want.norm()).item() < 1e-5
         torch.testing.assert_close(env["tuf"]._contrastive_loss(c["sim_B"].cuda(), use_dcl=True).cpu(), c["loss_B_dcl"], rtol=1e-5, atol=1e-6)
 
 

@@ -10,7 +10,8 @@
  * names on top.
  *
  * Conventions
- *  - every pointer is a DEVICE pointer to contiguous row-major memory owned by the caller;
+ *  - every pointer is a DEVICE pointer to contiguous row-major memory owned by the caller
+ *    (the one exception, the parameter pointer lists of pclip_head_tail_*, says so);
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are
  *    enqueued on it and the call returns without synchronising;
  *  - nothing here allocates or frees device memory: scratch comes in through `ws`, sized
@@ -41,6 +42,7 @@ extern "C" {
 #define PCLIP_FILIP_MAX_D 128    /* FILIP token embedding width (zero-padded to 128)      */
 #define PCLIP_FILIP_MAX_T 256    /* FILIP tokens per sequence handled by the fast kernels */
 #define PCLIP_FILIP_MAX_T_LONG 4096 /* FILIP tokens per sequence at most (general kernel)  */
+#define PCLIP_HEAD_MAX_BLOCKS 4  /* Linear-ReLU-LayerNorm-Dropout blocks of the embedding head */
 
 int pclip_version(void);
 const char* pclip_last_error(void);
@@ -149,6 +151,34 @@ int pclip_filip_loss(const float* sim_A, const float* sim_B, int Br, int Bc, int
  * ------------------------------------------------------------------------------------- */
 int pclip_masked_mean_fwd(const float* h, const uint8_t* mask, int B, int T, int d, float* mean, float* inv_count, void* stream);
 int pclip_masked_mean_bwd(const float* g, const uint8_t* mask, const float* inv_count, int B, int T, int d, float* dh, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Embedding head of a CLIP tower, from the pooled vector to the scaled unit embedding.
+ * Replaces modules/models.py:49-51 with embedding_ffn as built at :54-73 (h2 - 1 blocks of
+ * Linear -> ReLU -> LayerNorm -> Dropout, then one Linear):
+ *   x_0 = pooled;  a_l = relu(W_l x_l + b_l);  x_{l+1} = (LayerNorm(a_l) * gamma_l + beta_l) * keep_l * keep_scale;
+ *   z = W_nblk x_nblk + b_nblk;  out = z / max(|z|, 1e-12) * exp(t / 2).
+ * pooled, out [B,d] f32; d % 4 == 0, d <= 128; nblk <= PCLIP_HEAD_MAX_BLOCKS.
+ * params: a HOST array of 4*nblk + 2 device pointers in module order: per block W [d,d] (row-major
+ *   [out][in], as nn.Linear holds it), b [d], gamma [d], beta [d]; then the last W and b.
+ * keep: the dropout masks [nblk,B,d] u8 (nonzero = kept) drawn by the caller, keep_scale = 1/(1-p);
+ *   NULL = no dropout (eval mode).  The reference draws them inside nn.Dropout from torch's
+ *   generator; which elements are dropped is the caller's random stream here, the arithmetic is the same.
+ * ln_eps: the LayerNorm epsilon (1e-5 in the reference's modules).
+ * save: pclip_head_tail_save_floats(B, d, nblk) floats kept for the backward (activations, row
+ *   statistics, z).  t: the temperature as a device scalar.
+ * Backward (autograd of the same lines): dout [B,d] -> dpooled [B,d] and dparams (host array of
+ * device pointers shaped and ordered like params), all OVERWRITTEN; dt is ACCUMULATED
+ * (dt += 0.5 * sum(out * dout)).  Two launches: rows, then parameter gradients (fixed summation
+ * order: results are reproducible except dt, which is met with float atomics).
+ * ------------------------------------------------------------------------------------- */
+size_t pclip_head_tail_save_floats(int B, int d, int nblk);
+size_t pclip_head_tail_bwd_workspace_bytes(int B, int d, int nblk);
+int pclip_head_tail_fwd(const float* pooled, const float* const* params, int nblk, const uint8_t* keep, float keep_scale,
+                        float ln_eps, const float* t, int B, int d, float* save, float* out, void* stream);
+int pclip_head_tail_bwd(const float* pooled, const float* const* params, int nblk, const uint8_t* keep, float keep_scale,
+                        const float* t, const float* save, const float* dout, int B, int d,
+                        float* dpooled, float* const* dparams, float* dt, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * FILIP token-wise similarity.

@@ -4,7 +4,7 @@ the read-only reference checkout is mounted — it does not exist on the GPU box
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [/root/reference]
 
-What is imported from the reference: ``modules.models`` (ExtendedFILIP static methods),
+What is imported from the reference: ``modules.models`` (ExtendedFILIP static methods, Encoder),
 ``modules.training_utils_filip`` and ``modules.training_utils``.  The last one imports the
 third-party ``grad_cache`` package, which is not vendored and not installable offline; a
 pass-through stand-in for its two decorators (list arguments concatenated on dim 0 /
@@ -290,6 +290,74 @@ def gen_topk(models, tu):
         json.dump(out, f, indent=1)
 
 
+def gen_head(models):
+    """The reference's ``Encoder`` (models.py:7-90) with a stand-in trunk that returns fixed hidden
+    states: everything after the per-residue network — masked mean, ``embedding_ffn``, normalise and
+    temperature scale — with its gradients.  In train mode the dropout masks that ``nn.Dropout``
+    drew inside ``embedding_ffn`` are recorded (output != 0) so the same elements can be dropped."""
+    class Trunk(torch.nn.Module):
+        def __init__(self, hidden):
+            super().__init__()
+            self.hidden = hidden
+
+        def forward(self, input_ids=None, attention_mask=None):
+            return types.SimpleNamespace(last_hidden_state=self.hidden)
+
+    flat = {}
+    for seed, (B, T, din, d), h2, p, train in [
+        (0, (37, 19, 24, 128), 2, 0.1, True),     # the reference's head (h2 = 2, dropout 0.1), ragged batch
+        (1, (16, 9, 16, 64), 3, 0.25, True),      # two blocks, narrower head
+        (2, (8, 5, 16, 128), 1, 0.1, False),      # a single Linear, eval mode
+        (3, (64, 12, 24, 128), 2, 0.1, False),    # eval mode: dropout is the identity
+    ]:
+        g = torch.Generator().manual_seed(seed)
+        hidden = torch.randn(B, T, din, generator=g)
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        mask = (torch.arange(T)[None] < lens[:, None]).long()
+        if seed == 0:
+            mask[3] = 0                                # a sequence with no valid token: the count clamps to 1
+        torch.manual_seed(100 + seed)
+        enc = models.Encoder(din, d, 2, h2, p, Trunk(hidden))
+        with torch.no_grad():                          # LayerNorm affine away from its (1, 0) initialisation
+            for m in enc.embedding_ffn.modules():
+                if isinstance(m, torch.nn.LayerNorm):
+                    m.weight.add_(0.2 * torch.randn(d, generator=g)); m.bias.add_(0.1 * torch.randn(d, generator=g))
+        enc.train(train)
+        seen = {}
+
+        def see_tokens(mod, inp, out):
+            out.retain_grad()
+            seen["tokens"] = out
+
+        def see_pooled(mod, inp):
+            inp[0].retain_grad()
+            seen["pooled"] = inp[0]
+        enc.amino_acid_ffn.register_forward_hook(see_tokens)
+        enc.embedding_ffn.register_forward_pre_hook(see_pooled)
+        keeps = []
+        for m in enc.embedding_ffn.modules():
+            if isinstance(m, torch.nn.Dropout):
+                def hook(mod, inp, out):
+                    assert not (inp[0] == 0).any()
+                    keeps.append((out != 0).to(torch.uint8) if mod.training else torch.ones_like(out, dtype=torch.uint8))
+                m.register_forward_hook(hook)
+        t = torch.tensor(0.6 + 0.2 * seed, requires_grad=True)
+        out = enc({"input_ids": None, "attention_mask": mask, "temperature": t})
+        w = torch.randn(B, d, generator=g)
+        (out * w).sum().backward()
+        key = f"s{seed}_B{B}_T{T}_d{d}_h{h2}_{'train' if train else 'eval'}"
+        c = dict(tokens=_np(seen["tokens"]), mask=_np(mask).astype(np.uint8), pooled=_np(seen["pooled"]), t=np.float32(t.item()),
+                 p=np.float32(p), train=np.uint8(train), out=_np(out), d_out=_np(w), d_tokens=_np(seen["tokens"].grad),
+                 d_pooled=_np(seen["pooled"].grad), d_t=_np(t.grad))
+        if keeps:
+            c["keep"] = _np(torch.stack(keeps))
+        for name, prm in enc.embedding_ffn.named_parameters():
+            c["param:" + name] = _np(prm)
+            c["grad:" + name] = _np(prm.grad)
+        flat.update({f"{key}/{f}": v for f, v in c.items()})
+    np.savez_compressed(os.path.join(OUT, "head_tail.npz"), **flat)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.dont_write_bytecode = True
@@ -300,6 +368,10 @@ def main():
     import modules.models as models
     import modules.training_utils as tu
     import modules.training_utils_filip as tuf
+    if "--head-only" in sys.argv:
+        gen_head(models)
+        print("head fixtures written", flush=True)
+        return
     if "--ties-topk-only" in sys.argv:
         gen_ties(models, tuf)
         gen_topk(models, tu)
@@ -308,6 +380,7 @@ def main():
     if "--loops-only" not in sys.argv:
         gen_ties(models, tuf)
         gen_topk(models, tu)
+        gen_head(models)
         gen_clip(tu)
         print("clip goldens written", flush=True)
         gen_filip(models, tuf)

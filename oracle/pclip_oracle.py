@@ -26,6 +26,50 @@ from typing import List, Sequence, Tuple
 import torch
 
 # --------------------------------------------------------------------------------------
+# CLIP tower head: pooling, embedding_ffn, normalise
+# --------------------------------------------------------------------------------------
+
+
+def encoder_masked_mean(h: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """``Encoder._masked_mean`` (modules/models.py:76-90): the mask multiplies by VALUE and the
+    token count is clamped to at least 1."""
+    m = mask.to(h.dtype)
+    return (h * m.unsqueeze(-1)).sum(dim=1) / m.sum(dim=1, keepdim=True).clamp(min=1)
+
+
+def head_tail(pooled: torch.Tensor, params: Sequence[torch.Tensor], keep, keep_scale: float, ln_eps: float,
+              temperature: torch.Tensor) -> torch.Tensor:
+    """``embedding_ffn`` then normalise and scale (modules/models.py:49-51; the network is built at
+    :54-73: blocks of Linear -> ReLU -> LayerNorm -> Dropout, then one Linear).  ``params`` lists
+    ``W, b, gamma, beta`` per block and the last ``W, b``; ``keep [blocks,B,d]`` holds the dropout
+    masks (None = eval mode), a kept element is multiplied by ``keep_scale = 1 / (1 - p)``.
+    LayerNorm uses the biased variance, as ``nn.LayerNorm`` does."""
+    x = pooled
+    for l in range((len(params) - 2) // 4):
+        W, b, gamma, beta = params[4 * l:4 * l + 4]
+        a = (x @ W.t() + b).clamp(min=0)
+        mu = a.mean(dim=-1, keepdim=True)
+        var = (a - mu).pow(2).mean(dim=-1, keepdim=True)
+        x = (a - mu) / torch.sqrt(var + ln_eps) * gamma + beta
+        if keep is not None:
+            x = x * keep[l].to(x.dtype) * keep_scale
+    return l2norm_scale(x @ params[-2].t() + params[-1], temperature)
+
+
+def head_step(tokens, mask, params, keep, keep_scale, ln_eps, temperature, d_out):
+    """Forward and the gradients autograd returns for ``sum(out * d_out)``:
+    ``(out, pooled, d_tokens, d_pooled, [d_param ...], d_t)``."""
+    tok = tokens.detach().clone().requires_grad_(True)
+    prm = [p.detach().clone().requires_grad_(True) for p in params]
+    t = temperature.detach().clone().requires_grad_(True)
+    pooled = encoder_masked_mean(tok, mask)
+    pooled.retain_grad()
+    out = head_tail(pooled, prm, keep, keep_scale, ln_eps, t)
+    (out * d_out).sum().backward()
+    return out.detach(), pooled.detach(), tok.grad, pooled.grad, [p.grad for p in prm], t.grad
+
+
+# --------------------------------------------------------------------------------------
 # CLIP
 # --------------------------------------------------------------------------------------
 

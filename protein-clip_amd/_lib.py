@@ -35,6 +35,10 @@ _SIGNATURES = {
     "pclip_filip_loss": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "pclip_masked_mean_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "pclip_masked_mean_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "pclip_head_tail_save_floats": (c_size_t, [c_int, c_int, c_int]),
+    "pclip_head_tail_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pclip_head_tail_fwd": (c_int, [_P, _P, c_int, _P, c_float, c_float, _P, c_int, c_int, _P, _P, _P]),
+    "pclip_head_tail_bwd": (c_int, [_P, _P, c_int, _P, c_float, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "pclip_filip_prep": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pclip_filip_sim_fwd": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P]),
     "pclip_filip_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -76,6 +76,64 @@ def masked_mean_bwd(g: torch.Tensor, m8: torch.Tensor, inv: torch.Tensor, T: int
     return dh
 
 
+# ---- embedding head after the pooling -----------------------------------------------------
+HEAD_MAX_BLOCKS = 4
+HEAD_MAX_D = 128
+
+
+def _head_pointers(tensors):
+    """Host array of device pointers, in the order the library expects."""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _head_check(pooled, params, keep):
+    require_gpu_tensor(pooled, F32, "pooled")
+    B, d = pooled.shape
+    if len(params) < 2 or (len(params) - 2) % 4:
+        raise _lib.PclipError("head_tail: expected 4 tensors per block (W, b, gamma, beta) and the last W, b")
+    nblk = (len(params) - 2) // 4
+    for i, prm in enumerate(params):
+        require_gpu_tensor(prm, F32, f"params[{i}]")
+        want = (d, d) if (i % 4 == 0) else (d,)
+        if tuple(prm.shape) != want:
+            raise _lib.PclipError(f"head_tail: params[{i}] has shape {tuple(prm.shape)}, expected {want}")
+    if keep is not None:
+        require_gpu_tensor(keep, torch.uint8, "keep")
+        if tuple(keep.shape) != (nblk, B, d):
+            raise _lib.PclipError(f"head_tail: keep has shape {tuple(keep.shape)}, expected {(nblk, B, d)}")
+    return B, d, nblk
+
+
+def head_tail_fwd(pooled, params, keep, keep_scale: float, ln_eps: float, t):
+    """pooled [B,d]; params = [W, b, gamma, beta] per block + [W, b]; keep [nblk,B,d] u8 or None.
+    Returns (out [B,d], save) with ``save`` the activations the backward needs."""
+    B, d, nblk = _head_check(pooled, params, keep)
+    lib = _lib.load()
+    tt = _scalar(t, pooled.device, "t")
+    save = torch.empty(lib.pclip_head_tail_save_floats(B, d, nblk), dtype=F32, device=pooled.device)
+    out = torch.empty_like(pooled)
+    check(lib.pclip_head_tail_fwd(ptr(pooled), _head_pointers(params), nblk, ptr(keep), float(keep_scale), float(ln_eps), ptr(tt), B, d,
+                                  ptr(save), ptr(out), stream_of(pooled)), "pclip_head_tail_fwd")
+    return out, save
+
+
+def head_tail_bwd(pooled, params, keep, keep_scale: float, ln_eps: float, t, save, dout, dt: Optional[torch.Tensor] = None):
+    """Returns (dpooled, [gradient of each tensor of ``params``], dt); a given ``dt`` is accumulated into."""
+    B, d, nblk = _head_check(pooled, params, keep)
+    require_gpu_tensor(dout, F32, "dout")
+    require_gpu_tensor(save, F32, "save")
+    lib = _lib.load()
+    tt = _scalar(t, pooled.device, "t")
+    dpooled = torch.empty_like(pooled)
+    dparams = [torch.empty_like(prm) for prm in params]
+    if dt is None:
+        dt = torch.zeros(1, dtype=F32, device=pooled.device)
+    ws = _workspace(pooled.device, lib.pclip_head_tail_bwd_workspace_bytes(B, d, nblk))
+    check(lib.pclip_head_tail_bwd(ptr(pooled), _head_pointers(params), nblk, ptr(keep), float(keep_scale), ptr(tt), ptr(save), ptr(dout), B, d,
+                                  ptr(dpooled), _head_pointers(dparams), ptr(dt), ptr(ws), ws.numel(), stream_of(pooled)), "pclip_head_tail_bwd")
+    return dpooled, dparams, dt
+
+
 # ---- L2 normalise + scale ---------------------------------------------------------------
 def l2norm_scale_fwd(e: torch.Tensor, t) -> torch.Tensor:
     require_gpu_tensor(e, F32, "e")

@@ -5,8 +5,9 @@ LayerNorm / ReLU / Dropout).  The lines of the reference that sit on the contras
 are replaced by HIP operators:
 
 * ``Encoder._masked_mean`` (models.py:76-90) -> :func:`protein_clip_amd.ops.masked_mean`;
-* ``Encoder.forward`` tail, ``F.normalize(e) * exp(t/2)`` (models.py:50-51)
-  -> :func:`protein_clip_amd.ops.l2norm_scale`;
+* ``Encoder.forward`` tail, ``embedding_ffn`` and ``F.normalize(e) * exp(t/2)`` (models.py:49-51)
+  -> :func:`protein_clip_amd.ops.embedding_head` (one launch; the layers stay ordinary
+  ``nn.Linear`` / ``nn.LayerNorm`` modules that own the parameters);
 * ``ExtendedFILIP.forward`` token normalisation + ``_filip_similarity_score``
   (models.py:237-243, 292-356) -> :func:`protein_clip_amd.ops.filip_similarity`.
 
@@ -37,6 +38,33 @@ def _token_features(tower, seq):
     return tower.amino_acid_ffn(tower.projection(hidden))
 
 
+def _head_layout(ffn: nn.Sequential):
+    """``(params, dropout_p, ln_eps)`` when ``ffn`` has the layout ``_feed_forward`` builds (blocks of
+    Linear -> ReLU -> LayerNorm -> Dropout, then one Linear, square, within the fused kernel's
+    limits), else None."""
+    mods = list(ffn)
+    if not mods or not isinstance(mods[-1], nn.Linear) or len(mods) - 1 > ops.HEAD_MAX_BLOCKS:
+        return None
+    width = mods[-1].in_features
+    params, p, eps = [], 0.0, 1e-5
+    for blk in mods[:-1]:
+        if not (isinstance(blk, nn.Sequential) and len(blk) == 4 and isinstance(blk[0], nn.Linear) and isinstance(blk[1], nn.ReLU)
+                and isinstance(blk[2], nn.LayerNorm) and isinstance(blk[3], nn.Dropout)):
+            return None
+        if blk[0].bias is None or not blk[2].elementwise_affine or blk[2].bias is None or tuple(blk[2].normalized_shape) != (width,):
+            return None
+        params += [blk[0].weight, blk[0].bias, blk[2].weight, blk[2].bias]
+        p, eps = blk[3].p, blk[2].eps
+    if mods[-1].bias is None:
+        return None
+    params += [mods[-1].weight, mods[-1].bias]
+    if any(tuple(w.shape) != (width, width) for w in params[0::4]) or width % 4 or width > ops.HEAD_MAX_D:
+        return None
+    if len({(blk[3].p, blk[2].eps) for blk in mods[:-1]}) > 1:
+        return None
+    return params, p, eps
+
+
 class Encoder(nn.Module):
     """One CLIP tower: trunk -> projection -> per-residue FFN -> masked mean -> FFN ->
     unit-norm embedding scaled by exp(temperature / 2)."""
@@ -51,7 +79,17 @@ class Encoder(nn.Module):
     def forward(self, seq):
         """``seq``: mapping with ``input_ids``, ``attention_mask`` and ``temperature``."""
         pooled = self._masked_mean(_token_features(self, seq), seq["attention_mask"])
-        return ops.l2norm_scale(self.embedding_ffn(pooled), seq["temperature"])
+        layout = _head_layout(self.embedding_ffn)
+        if layout is None:   # a head of another shape: its own modules, then the normalise kernel
+            return ops.l2norm_scale(self.embedding_ffn(pooled), seq["temperature"])
+        params, p, eps = layout
+        blocks = len(self.embedding_ffn) - 1
+        keep, scale = None, 1.0
+        if self.training and p > 0.0 and blocks > 0:
+            # nn.Dropout's element-wise Bernoulli(1 - p) masks, drawn from torch's generator of this device
+            keep = (torch.rand((blocks,) + tuple(pooled.shape), device=pooled.device) >= p).to(torch.uint8)
+            scale = 1.0 / (1.0 - p) if p < 1.0 else 0.0
+        return ops.embedding_head(pooled, params, seq["temperature"], keep, scale, eps)
 
     _build_ffn = staticmethod(_feed_forward)
 

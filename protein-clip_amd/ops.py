@@ -99,6 +99,39 @@ def masked_mean(h: torch.Tensor, mask: torch.Tensor, kernels=None) -> torch.Tens
     return _MaskedMean.apply(_f32(h), mask, kernels or _hip_kernels)
 
 
+# limits of the fused embedding-head kernel (PCLIP_HEAD_MAX_BLOCKS, and its width, in include/pclip.h)
+HEAD_MAX_BLOCKS = _hip_kernels.HEAD_MAX_BLOCKS
+HEAD_MAX_D = _hip_kernels.HEAD_MAX_D
+
+
+class _HeadTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pooled, t, keep, keep_scale, ln_eps, K, *params):
+        pooled = pooled.contiguous()
+        params = [prm.detach().contiguous() for prm in params]
+        out, save = K.head_tail_fwd(pooled, params, keep, keep_scale, ln_eps, t)
+        ctx.K, ctx.keep, ctx.keep_scale, ctx.ln_eps, ctx.n = K, keep, keep_scale, ln_eps, len(params)
+        ctx.save_for_backward(pooled, t, save, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        pooled, t, save = ctx.saved_tensors[:3]
+        params = list(ctx.saved_tensors[3:])
+        dpooled, dparams, dt = ctx.K.head_tail_bwd(pooled, params, ctx.keep, ctx.keep_scale, ctx.ln_eps, t, save, dout.contiguous())
+        return (dpooled, dt.reshape(t.shape).to(t.dtype), None, None, None, None) + tuple(dparams)
+
+
+def embedding_head(pooled: torch.Tensor, params, temperature: torch.Tensor, keep: Optional[torch.Tensor] = None, keep_scale: float = 1.0,
+                   ln_eps: float = 1e-5, kernels=None) -> torch.Tensor:
+    """The embedding head of a CLIP tower after the pooling (modules/models.py:49-51 with
+    ``embedding_ffn`` as built at :54-73) as one launch forward and two backward:
+    ``params`` = ``[W, b, gamma, beta]`` of each Linear -> ReLU -> LayerNorm -> Dropout block, then
+    ``[W, b]`` of the last Linear; ``keep`` = the dropout masks ``[blocks, B, d]`` (uint8, None in
+    eval mode) with ``keep_scale = 1 / (1 - p)``.  Returns ``normalize(z) * exp(temperature / 2)``."""
+    return _HeadTail.apply(_f32(pooled), _f32(temperature), keep, float(keep_scale), float(ln_eps), kernels or _hip_kernels, *params)
+
+
 def l2norm_scale(e: torch.Tensor, temperature: torch.Tensor, kernels=None) -> torch.Tensor:
     """``F.normalize(e, dim=-1) * torch.exp(temperature / 2)`` as one kernel each way."""
     return _L2NormScale.apply(_f32(e), _f32(temperature), kernels or _hip_kernels)

@@ -40,3 +40,22 @@ def clip_cases():
 @pytest.fixture(scope="session")
 def filip_cases():
     return load_cases("filip_small.npz")
+
+
+def head_case_params(c):
+    """The parameter list of a head fixture case in module order (W, b, gamma, beta per block, then the
+    last W, b), the matching gradients, the dropout masks (or None) and 1 / (1 - p)."""
+    names = sorted((k[6:] for k in c if k.startswith("param:")), key=lambda n: [int(v) if v.isdigit() else v for v in n.split(".")])
+    # names: "0.0.weight", "0.0.bias", "0.2.weight", "0.2.bias", ..., "<last>.weight", "<last>.bias"
+    order = sorted(names, key=lambda n: (int(n.split(".")[0]), n.split(".")[1] if n.count(".") == 2 else "", 0 if n.endswith("weight") else 1))
+    params = [c["param:" + n] for n in order]
+    grads = [c["grad:" + n] for n in order]
+    train = bool(c["train"].item())
+    keep = c["keep"] if (train and "keep" in c) else None
+    scale = 1.0 / (1.0 - float(c["p"])) if train else 1.0
+    return params, grads, keep, scale
+
+
+@pytest.fixture(scope="session")
+def head_cases():
+    return load_cases("head_tail.npz")

@@ -26,6 +26,34 @@ def masked_mean_bwd(g, m8, inv, T):
     return m8.to(F32)[..., None] * (g * inv[:, None])[:, None, :]
 
 
+def _head(pooled, params, keep, keep_scale, ln_eps, tval):
+    x = pooled
+    nblk = (len(params) - 2) // 4
+    for l in range(nblk):
+        W, b, g, be = params[4 * l:4 * l + 4]
+        a = torch.relu(x @ W.t() + b)
+        x = torch.nn.functional.layer_norm(a, (a.shape[-1],), g, be, ln_eps)
+        if keep is not None:
+            x = x * keep[l].to(F32) * keep_scale
+    return _l2(x @ params[-2].t() + params[-1], tval)
+
+
+def head_tail_fwd(pooled, params, keep, keep_scale, ln_eps, t):
+    return _head(pooled, params, keep, keep_scale, ln_eps, _s(t)), torch.empty(0)
+
+
+def head_tail_bwd(pooled, params, keep, keep_scale, ln_eps, t, save, dout, dt=None):
+    leaves = [v.detach().clone().requires_grad_(True) for v in [pooled] + list(params)]
+    t_ = _s(t).detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        (_head(leaves[0], leaves[1:], keep, keep_scale, ln_eps, t_) * dout).sum().backward()
+    out_dt = t_.grad.reshape(1)
+    if dt is not None:
+        dt += out_dt
+        out_dt = dt
+    return leaves[0].grad, [v.grad for v in leaves[1:]], out_dt
+
+
 def l2norm_scale_fwd(e, t):
     return _l2(e, _s(t))
 

@@ -5,7 +5,7 @@ import math
 import pytest
 import torch
 
-from conftest import load_flat
+from conftest import head_case_params, load_flat
 from oracle import pclip_oracle as O
 from routing_ref import decode_image, routed_grads
 
@@ -41,6 +41,84 @@ def mostly_close(a, b, rtol, atol, max_bad_frac=0.0, max_rel_l2=None):
     if max_rel_l2 is not None:
         rel = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
         assert rel <= max_rel_l2, f"relative L2 error {rel:.3e} > {max_rel_l2:.1e}"
+
+
+# ------------------------------------------------------------------------------------------
+# embedding head: pooling -> Linear/ReLU/LayerNorm/Dropout blocks -> Linear -> normalise, scale
+# ------------------------------------------------------------------------------------------
+def test_head_tail_matches_the_reference_encoder(K, head_cases):
+    """The reference's Encoder after the per-residue network (models.py:48-51), values and every
+    gradient, with the dropout masks the reference drew."""
+    for key, c in head_cases.items():
+        params, grads, keep, scale = head_case_params(c)
+        tokens, t = dev(c["tokens"]), dev(c["t"].reshape(1))
+        pooled, inv, m8 = K.masked_mean_fwd(tokens, dev(c["mask"]))
+        close(pooled, c["pooled"], 1e-5, 1e-6)
+        P = [dev(p) for p in params]
+        kp = None if keep is None else dev(keep)
+        out, save = K.head_tail_fwd(pooled, P, kp, scale, 1e-5, t)
+        close(out, c["out"], 1e-4, 1e-6)
+        d_pooled, d_params, d_t = K.head_tail_bwd(pooled, P, kp, scale, 1e-5, t, save, dev(c["d_out"]))
+        close(d_pooled, c["d_pooled"], 2e-4, 2e-6)
+        close(d_t, c["d_t"].reshape(1), 2e-4, 1e-5)
+        for g, want in zip(d_params, grads):
+            close(g, want, 2e-4, 2e-5)
+        close(K.masked_mean_bwd(d_pooled, m8, inv, tokens.shape[1]), c["d_tokens"], 2e-4, 2e-6)
+
+
+@pytest.mark.parametrize("B,d,nblk,p", [(256, 128, 1, 0.1), (1024, 128, 1, 0.1), (7, 128, 4, 0.5), (33, 64, 0, 0.0), (300, 96, 2, 0.0), (1, 4, 1, 0.3)])
+def test_head_tail_against_the_oracle(K, B, d, nblk, p):
+    """Benchmark batch sizes, the deepest head the kernel takes, a lone Linear, narrow and odd widths:
+    against the oracle in float64 (f32 kernel: 1e-5 of the largest magnitude per tensor)."""
+    g = torch.Generator().manual_seed(B + d + nblk)
+    pooled = torch.randn(B, d, generator=g)
+    params = []
+    for l in range(nblk):
+        params += [torch.randn(d, d, generator=g) / math.sqrt(d), 0.1 * torch.randn(d, generator=g), 1 + 0.2 * torch.randn(d, generator=g),
+                   0.1 * torch.randn(d, generator=g)]
+    params += [torch.randn(d, d, generator=g) / math.sqrt(d), 0.1 * torch.randn(d, generator=g)]
+    keep = (torch.rand(nblk, B, d, generator=g) >= p).to(torch.uint8) if p > 0 else None
+    scale = 1.0 / (1.0 - p)
+    t = torch.tensor(0.9)
+    d_out = torch.randn(B, d, generator=g)
+    leaves = [v.double().requires_grad_(True) for v in [pooled] + params]
+    t64 = t.double().requires_grad_(True)
+    want = O.head_tail(leaves[0], leaves[1:], keep, scale, 1e-5, t64)
+    (want * d_out.double()).sum().backward()
+
+    P = [dev(v) for v in params]
+    kp = None if keep is None else dev(keep)
+    out, save = K.head_tail_fwd(dev(pooled), P, kp, scale, 1e-5, dev(t.reshape(1)))
+    dt = torch.full((1,), 0.25, device="cuda")                      # accumulated into
+    d_pooled, d_params, dt2 = K.head_tail_bwd(dev(pooled), P, kp, scale, 1e-5, dev(t.reshape(1)), save, dev(d_out), dt=dt)
+    assert dt2 is dt
+
+    def near(a, b, rel=1e-5):
+        b = b.detach()
+        err = (a.detach().cpu().double().reshape(b.shape) - b).abs().max().item()
+        assert err <= rel * max(b.abs().max().item(), 1e-3), f"max error {err:.3e} against magnitude {b.abs().max().item():.3e}"
+    # a LayerNorm over four values, most of them clipped to zero, is ill-conditioned: looser there
+    grad_rel = 2e-5 if d >= 64 else 2e-3
+    near(out, want)
+    near(d_pooled, leaves[0].grad, grad_rel)
+    for got, leaf in zip(d_params, leaves[1:]):
+        near(got, leaf.grad, grad_rel)
+    # dt is a sum over rows of terms of either sign: the f32 error scales with the sum of magnitudes
+    terms = 0.5 * (want.detach() * d_out.double()).sum(1)
+    assert abs((dt - 0.25).item() - t64.grad.item()) <= 1e-6 * terms.abs().sum().item() + 1e-7
+
+
+def test_head_tail_rejects_what_it_cannot_run(K):
+    from protein_clip_amd._lib import PclipError
+    x = torch.randn(8, 130, device="cuda")
+    with pytest.raises(PclipError):
+        K.head_tail_fwd(x, [torch.randn(130, 130, device="cuda"), torch.randn(130, device="cuda")], None, 1.0, 1e-5, torch.ones(1, device="cuda"))
+    x = torch.randn(8, 128, device="cuda")
+    blocks = [torch.randn(128, 128, device="cuda"), torch.randn(128, device="cuda"), torch.ones(128, device="cuda"), torch.zeros(128, device="cuda")] * 5
+    with pytest.raises(PclipError):
+        K.head_tail_fwd(x, blocks + [torch.randn(128, 128, device="cuda"), torch.randn(128, device="cuda")], None, 1.0, 1e-5, torch.ones(1, device="cuda"))
+    with pytest.raises(PclipError):   # CPU tensors are not taken
+        K.head_tail_fwd(x.cpu(), [torch.randn(128, 128), torch.randn(128)], None, 1.0, 1e-5, torch.ones(1))
 
 
 # ------------------------------------------------------------------------------------------

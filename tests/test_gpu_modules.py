@@ -8,6 +8,7 @@ import pytest
 import torch
 from torch.utils.data import DataLoader
 
+from conftest import head_case_params
 from oracle import pclip_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -208,3 +209,39 @@ def test_operators_accept_half_precision_activations(env):
         assert total.dtype == torch.float32 and torch.isfinite(total)
         for x in (e1, e2, hA, hB):
             assert x.grad is not None and x.grad.dtype == dt and torch.isfinite(x.grad.float()).all()
+
+
+def test_encoder_tail_matches_the_reference_encoder(env, head_cases, monkeypatch):
+    """``Encoder.forward`` from the per-residue features on (models.py:48-51) against the reference's
+    Encoder run with a stand-in trunk: the fused head is what ``forward`` calls, in eval mode and in
+    train mode with the dropout masks the reference drew (fed through the ``torch.rand`` the tower
+    draws its masks from)."""
+    import types
+    models = env["models"]
+    for key, c in head_cases.items():
+        params, grads, keep, scale = head_case_params(c)
+        d, h2 = c["pooled"].shape[1], (len(params) - 2) // 4 + 1
+        tokens = c["tokens"].cuda().requires_grad_(True)
+
+        class Trunk(torch.nn.Module):
+            def forward(self, input_ids=None, attention_mask=None):
+                return types.SimpleNamespace(last_hidden_state=tokens)
+        enc = models.Encoder(d, d, 1, h2, float(c["p"]), Trunk()).cuda()
+        enc.projection = torch.nn.Identity()
+        enc.amino_acid_ffn = torch.nn.Identity()
+        assert models._head_layout(enc.embedding_ffn) is not None
+        with torch.no_grad():
+            for prm, val in zip(models._head_layout(enc.embedding_ffn)[0], params):
+                prm.copy_(val)
+        enc.train(bool(c["train"].item()))
+        if keep is not None:
+            monkeypatch.setattr(torch, "rand", lambda shape, device=None: keep.to(device=device, dtype=torch.float32))
+        t = c["t"].clone().cuda().requires_grad_(True)
+        out = enc({"input_ids": None, "attention_mask": c["mask"].cuda(), "temperature": t})
+        monkeypatch.undo()
+        torch.testing.assert_close(out.cpu(), c["out"], rtol=1e-4, atol=1e-6)
+        (out * c["d_out"].cuda()).sum().backward()
+        torch.testing.assert_close(tokens.grad.cpu(), c["d_tokens"], rtol=2e-4, atol=2e-6)
+        torch.testing.assert_close(t.grad.cpu(), c["d_t"], rtol=2e-4, atol=1e-5)
+        for prm, want in zip(models._head_layout(enc.embedding_ffn)[0], grads):
+            torch.testing.assert_close(prm.grad.cpu(), want, rtol=2e-4, atol=2e-5)

@@ -4,7 +4,7 @@ import torch
 import pytest
 
 from oracle import pclip_oracle as O
-from conftest import load_flat
+from conftest import load_flat, head_case_params
 
 
 def close(a, b, rtol, atol):
@@ -149,3 +149,23 @@ def test_topk_eval_host_logic_against_the_reference_ranks():
             assert got == want["ranks"][str(k)], (k, got, want["ranks"][str(k)], want["diag"][str(k)])
     finally:
         ops._hip_kernels = real
+
+
+def test_head_tail_cases(head_cases):
+    """Pooling, embedding_ffn, normalise and scale of the reference's Encoder (forward in f32, gradients
+    checked in f64 as well): values, and every gradient autograd returned."""
+    assert len(head_cases) == 4
+    for key, c in head_cases.items():
+        params, grads, keep, scale = head_case_params(c)
+        assert len(params) == 4 * (int(key.split("_h")[1].split("_")[0]) - 1) + 2
+        for dt_, rtol, atol in ((torch.float32, 2e-4, 2e-6), (torch.float64, 2e-4, 2e-6)):
+            cast = lambda v: v.to(dt_)
+            out, pooled, d_tok, d_pool, d_prm, d_t = O.head_step(cast(c["tokens"]), c["mask"], [cast(p) for p in params], keep, scale, 1e-5,
+                                                                 cast(c["t"]), cast(c["d_out"]))
+            close(pooled.float(), c["pooled"], 1e-5, 1e-6)
+            close(out.float(), c["out"], 1e-4, 1e-6)
+            close(d_pool.float(), c["d_pooled"], rtol, atol)
+            close(d_tok.float(), c["d_tokens"], rtol, atol)
+            close(d_t.float(), c["d_t"], rtol, 1e-5)
+            for g, want in zip(d_prm, grads):
+                close(g.float(), want, rtol, 2e-5)

@@ -19,7 +19,8 @@
 // column maxima, ONE key per element for both sides (one v_lshl_or_b32).  Row and column
 // maxima are integer maxima of these keys; nothing of the value is dropped, a maximum differs
 // from the exact one only by the f32 rounding of the accumulation near 4 (ulp 2.4e-7 / 4.8e-7).
-// Padding columns and rows get a negative key.  Column maxima of the A tiles held by different waves
+// Padding columns get a negative key; padding rows of an A tile are fed as copies of a valid row (no
+// masking, the winner is mapped back).  Column maxima of the A tiles held by different waves
 // meet in LDS through a
 // 64-bit integer atomic max (key in the high word, A tile and lane half in the low word).
 // Rows finish once per (A tile, B sequence) by transposing the 32x32 keys through a per-wave
@@ -139,22 +140,11 @@ __device__ __forceinline__ void row_fold(const int (&key)[16], int (&KM)[16]) {
     for (int r = 0; r < 16; ++r) KM[r] = FRESH ? key[r] : max(KM[r], key[r]);
 }
 
-// Column side: one dependent chain of max3.  APART: some rows of the A tile are padding; their
-// keys are kept out through the lane masks rm[r] (bit l = row of register r is valid in lane l;
-// what they add to the row maxima of padding rows is never read).
-template <bool APART>
-__device__ __forceinline__ int col_max(const int (&key)[16], const unsigned long long (&rm)[16]) {
-    int cb = NEG_KEY;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        int k0 = key[r], k1 = key[r + 1];
-        if (APART) {
-            k0 = __builtin_amdgcn_inverse_ballot_w64(rm[r]) ? k0 : NEG_KEY;
-            k1 = __builtin_amdgcn_inverse_ballot_w64(rm[r + 1]) ? k1 : NEG_KEY;
-        }
-        cb = max3_i(cb, k0, k1);
-    }
-    return cb;
+// Column side: a tree of max3, depth three (padding rows of the A tile hold copies of a valid row).
+__device__ __forceinline__ int col_max(const int (&key)[16]) {
+    const int a0 = max3_i(key[0], key[1], key[2]), a1 = max3_i(key[3], key[4], key[5]), a2 = max3_i(key[6], key[7], key[8]);
+    const int a3 = max3_i(key[9], key[10], key[11]), a4 = max3_i(key[12], key[13], key[14]);
+    return max3_i(max3_i(a0, a1, a2), max3_i(a3, a4, key[15]), NEG_KEY);
 }
 
 template <int N>
@@ -314,22 +304,17 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     }
     bf16x8 afr[8];
     {
-        const uint16_t* src = p.hnA + ((size_t)max(ISEQ(slot_isel), 0) * p.TAp + slot_at * 32 + c) * FD + 8 * h;
+        // A padding row of the tile is fed as a COPY of the tile's lowest valid row: its products repeat that row's
+        // exactly, so no column maximum changes and no row of the tile has to be masked out of the column side; a
+        // column winner that is such a copy is mapped back to the row it copies where the columns are finished.
+        const int arow = ((wA >> c) & 1u) ? c : __builtin_ctz(wA | 0x80000000u);
+        const uint16_t* src = p.hnA + ((size_t)max(ISEQ(slot_isel), 0) * p.TAp + slot_at * 32 + arow) * FD + 8 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) afr[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
     }
     // retire the A-fragment loads here (an opaque use), before any LDS-DMA is in flight
 #pragma unroll
     for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(afr[s]));
-
-    // lane masks of the A tile's valid rows, one per accumulator register (scalar registers)
-    unsigned long long rm[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const uint32_t lo = ((wA >> acc_row(r, 0)) & 1u) ? 0xffffffffu : 0u, hi = ((wA >> acc_row(r, 1)) & 1u) ? 0xffffffffu : 0u;
-        rm[r] = ((unsigned long long)hi << 32) | lo;
-    }
-    const bool apart = wA != 0xffffffffu;
 
     const int T = __builtin_amdgcn_readfirstlane(cnt_l[0]);
     const int nE = T / SE;
@@ -343,22 +328,26 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     const int piece = w & 7, dq = w >> 3;
     const unsigned char* hnB_bytes = reinterpret_cast<const unsigned char*>(p.hnB);
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + C::S_RING) + (uint32_t)piece * 1024u;
-    auto issue_epoch = [&](int E) {
-        // the lane's source offset is recomputed here from an opaque lane id, so that it does not
-        // occupy registers (or a scratch slot) across the whole tile loop
-        int ln;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-        const uint32_t dsrc_off = (uint32_t)((ln & 31) * (FD * 2) + 32 * piece + 16 * (ln >> 5));
+    // the lane's part of the source address: token ln % 32, k-step `piece`, half ln / 32
+    const uint32_t dsrc_off = (uint32_t)(c * (FD * 2) + 32 * piece + 16 * h);
+    // g[k]: index of the tile (among all 32-token tiles of hnB) that wave-local DMA k of the epoch fetches
+    auto issue_epoch = [&](int E, const uint32_t (&g)[SE / 2]) {
 #pragma unroll
         for (int k = 0; k < SE / 2; ++k) {   // SE * 8 pieces per epoch over 16 waves
             const int tq = dq + 2 * k;
-            const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[E * SE + tq].y);
-            const unsigned char* src = hnB_bytes + (size_t)g * (32 * FD * 2) + dsrc_off;
+            const unsigned char* src = hnB_bytes + (size_t)g[k] * (32 * FD * 2);   // scalar
             const uint32_t dst = ring_lds + (uint32_t)((E % SNE) * SE + tq) * TILE_BYTES;
             uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(dsrc_off), "s"(src), "s"(dst) : "memory");
         }
+    };
+    // The records of an epoch's tiles, read by eight lanes at once (lanes 0-3: the tiles of epoch E0, lanes 4-7:
+    // those of epoch E1) and handed out as scalars by v_readlane.
+    auto read_records = [&](int E0, int E1) { return meta[((lane & 4) ? E1 : E0) * SE + (lane & 3)]; };
+    auto dma_tiles = [&](const uint4& rec, int base_lane, uint32_t (&g)[SE / 2]) {
+#pragma unroll
+        for (int k = 0; k < SE / 2; ++k) g[k] = (uint32_t)__builtin_amdgcn_readlane((int)rec.y, base_lane + dq + 2 * k);
     };
 
     int KM[16];
@@ -367,8 +356,14 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     bool fresh = true;   // wave-uniform: no product of the current B sequence has been folded into KM yet
 
     // prologue: epochs 0 .. SNE-2 in flight, epoch 0 landed
+    static_assert(SE == 4, "the tile records of an epoch are read by four lanes");
     for (int E = 0; E < SNE - 1; ++E)
-        if (E < nE) issue_epoch(E);
+        if (E < nE) {
+            const uint4 rec = read_records(E, E);
+            uint32_t g[SE / 2];
+            dma_tiles(rec, 0, g);
+            issue_epoch(E, g);
+        }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
@@ -416,18 +411,21 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
 #endif
     for (int e = 0; e < nE; ++e) {
         const bool ahead = e + SNE - 1 < nE;
-        if (ahead) issue_epoch(e + SNE - 1);
+        // this epoch's tile records and the tiles of the epoch to fetch, as scalars
+        const uint4 rec = read_records(e, ahead ? e + SNE - 1 : e);
+        if (ahead) {
+            uint32_t g[SE / 2];
+            dma_tiles(rec, 4, g);
+            issue_epoch(e + SNE - 1, g);
+        }
         STAMP(0);
         const int ring0 = (e % SNE) * SE;
         const int par2 = e & 1, par3 = e % 3;
-
-        // this epoch's tile records, as scalars
         uint32_t t_wB[SE], t_mz[SE];   // column mask; B sequence | B tile << 8 | flags << 16
 #pragma unroll
         for (int q = 0; q < SE; ++q) {
-            const uint4 mraw = meta[e * SE + q];
-            t_wB[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mraw.x);
-            t_mz[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mraw.z);
+            t_wB[q] = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, q);
+            t_mz[q] = (uint32_t)__builtin_amdgcn_readlane((int)rec.z, q);
         }
         STAMP(1);
 
@@ -478,7 +476,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 if (fresh) row_fold<true>(key, KM);
                 else row_fold<false>(key, KM);
                 fresh = false;
-                const int cb = apart ? col_max<true>(key, rm) : col_max<false>(key, rm);
+                const int cb = col_max(key);
                 atomicMax(&col64[((par2 * SE + q) * 2 + slot_isel) * 32 + c], ((long long)cb << 32) | (long long)((slot_at << 1) | h));
 #endif
                 STAMP(3);
@@ -486,8 +484,12 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
             if ((fl & FLAG_LAST) && wA != 0) {
                 // ---- rows of the finished B sequence: transpose the keys, lane (row, half) scans 16 ----
                 int* tr = reinterpret_cast<int*>(smem + C::S_TR) + w * 32 * 36;
+                {
+                    int* trw = tr + 4 * h * 36 + c;
+                    asm volatile("" : "+v"(trw));   // the address arithmetic belongs to this branch, not to every product
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tr[acc_row(r, h) * 36 + c] = KM[r];
+                    for (int r = 0; r < 16; ++r) trw[((r & 3) + 8 * (r >> 2)) * 36] = KM[r];
+                }
                 const bool empty_b = fresh;   // an empty B sequence: nothing was folded in, KM is stale
                 fresh = true;
                 __builtin_amdgcn_wave_barrier();
@@ -559,7 +561,9 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                         cv = -FLT_MAX;
                     } else {
                         cv = key_value(hi);
-                        barg = (lo >> 1) * 32 + acc_row(hi & 15, lo & 1);
+                        const int at = lo >> 1, rr = acc_row(hi & 15, lo & 1);
+                        const uint32_t wd = mwa_l[isel * 8 + at];
+                        barg = at * 32 + (((wd >> rr) & 1u) ? rr : __builtin_ctz(wd | 0x80000000u));   // a copy -> the row it copies
                     }
                     if (p.argB)
                         p.argB[((size_t)ISEQ(isel) * p.Bc + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = (uint16_t)barg;

@@ -12,28 +12,7 @@
 // dot products unchanged.
 #include "pclip_common.h"
 
-struct ClipProb {
-    const float* A;     // [Br,d]  the caller's rows
-    const float* Bm;    // [Bc,d]  every row of the other side
-    int Br, Bc, off;    // the target column of row i is i + off
-    float2* part;       // fwd: [npart][Br] running (max, sum) per column split and wave
-    float* diag;        // fwd: [Br] S[i, i+off]
-    float* lse_out;     // fwd: [Br]
-    float* logits;      // fwd: optional [Br,Bc]
-    const float* lseA;  // bwd: [Br] log-sum-exp of the caller's rows
-    const float* lseB;  // bwd: [Bc] log-sum-exp of every column in the other direction
-    float* slab;        // bwd: [nsplit][Br][d] partial dA
-};
-
-struct ClipArgs {
-    ClipProb p[2];
-    int d;
-    int nsplit;
-    int tiles_per_split;
-    int logits_mode;
-    float scale;     // 0.5 / global batch
-    const float* g;  // optional upstream gradient (device scalar)
-};
+#include "clip_args.h"
 
 // T[j][i] for the 32 rows j0.. of Bm and the 32 rows i0.. of A.  Out-of-range rows are
 // clamped to the last valid row (finite garbage, masked by the callers).
@@ -71,6 +50,7 @@ __global__ __launch_bounds__(256) void clip_lse_kernel(ClipArgs args) {
     const int c = lane & 31, h = lane >> 5;
     const int d = args.d;
     const int i0 = blockIdx.x * 32;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *args.fin_counter = 0u;   // for the finalize launch behind this one
     if (i0 >= P.Br) return;
     const int irow = i0 + c;
     const bool ivalid = irow < P.Br;
@@ -122,33 +102,52 @@ __global__ __launch_bounds__(256) void clip_lse_kernel(ClipArgs args) {
     if (h == 0 && ivalid) P.part[(size_t)(blockIdx.y * 4 + w) * P.Br + irow] = make_float2(M, S);
 }
 
-// One block: merges the partial (max, sum) pairs into lse, and reduces the loss share
-// scale * sum_i (lse_row_i + lse_col_i - 2 S_ii) deterministically.
-__global__ __launch_bounds__(1024) void clip_finalize_kernel(ClipArgs args, float* __restrict__ loss_part) {
-    __shared__ float red[16];
-    const int npart = args.nsplit * 4;
+// Merges the partial (max, sum) pairs into lse, one thread per (direction, row), and reduces the loss share
+// scale * sum_i (lse_row_i + lse_col_i - 2 S_ii): every block leaves its partial sum, the block that arrives
+// last (a ticket, cleared by the score kernel in front of this launch) adds them up in block order, so the
+// result does not depend on the order in which the blocks ran.
+#define CLIP_FIN_THREADS 128
+__global__ __launch_bounds__(CLIP_FIN_THREADS) void clip_finalize_kernel(ClipArgs args, float* __restrict__ loss_part) {
+    __shared__ float red[CLIP_FIN_THREADS / 64];
+    __shared__ unsigned ticket;
+    const int npart = args.npart, Br = args.p[0].Br;
+    const int item = blockIdx.x * CLIP_FIN_THREADS + threadIdx.x;
     float acc = 0.f;
-    for (int z = 0; z < 2; ++z) {
-        const ClipProb& P = args.p[z];
-        for (int i = threadIdx.x; i < P.Br; i += 1024) {
-            float M = -FLT_MAX;
-            for (int k = 0; k < npart; ++k) M = fmaxf(M, P.part[(size_t)k * P.Br + i].x);
-            float S = 0.f;
-            for (int k = 0; k < npart; ++k) {
-                const float2 v = P.part[(size_t)k * P.Br + i];
-                S += v.y * expf(v.x - M);
+    if (item < 2 * Br) {
+        const ClipProb& P = args.p[item >= Br];
+        const int i = item >= Br ? item - Br : item;
+        const float2* part = P.part + i;
+        float M = -FLT_MAX, S = 0.f;
+        for (int k0 = 0; k0 < npart; k0 += 8) {   // eight partials requested at once, merged in order
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = k0 + u < npart ? part[(size_t)(k0 + u) * Br] : make_float2(-FLT_MAX, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float Mn = fmaxf(M, v[u].x);
+                S = S * expf(M - Mn) + v[u].y * expf(v[u].x - Mn);
+                M = Mn;
             }
-            const float lse = M + logf(S);
-            P.lse_out[i] = lse;
-            acc += lse - P.diag[i];
         }
+        const float lse = M + logf(S);
+        P.lse_out[i] = lse;
+        acc = lse - P.diag[i];
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         float v = 0.f;
-        for (int k = 0; k < 16; ++k) v += red[k];
+        for (int k = 0; k < CLIP_FIN_THREADS / 64; ++k) v += red[k];
+        args.fin_part[blockIdx.x] = v;
+        __threadfence();   // the partial sum is visible before the ticket is
+        ticket = atomicAdd(args.fin_counter, 1u);
+    }
+    __syncthreads();
+    if (ticket == gridDim.x - 1 && threadIdx.x == 0) {
+        __threadfence();
+        float v = 0.f;
+        for (unsigned k = 0; k < gridDim.x; ++k) v += __hip_atomic_load(args.fin_part + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         loss_part[0] = v * args.scale;
     }
 }
@@ -216,19 +215,44 @@ __global__ __launch_bounds__(256) void clip_grad_kernel(ClipArgs args) {
     }
 }
 
-// out[i] = sum over slabs
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int nslab, size_t stride, float* __restrict__ out,
-                                                       size_t n) {
-    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float v = 0.f;
-        for (int s = 0; s < nslab; ++s) v += slab[(size_t)s * stride + i];
+// out[i] = sum over slabs, 16 bytes per thread; blockIdx.y = side (slabs of side 1 follow those of side 0)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float4* __restrict__ slab, int nslab, size_t stride4, float4* __restrict__ out0,
+                                                       float4* __restrict__ out1, size_t n4) {
+    const float4* src = slab + (size_t)blockIdx.y * nslab * stride4;
+    float4* out = blockIdx.y ? out1 : out0;
+    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < nslab; s0 += 8) {
+            float4 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = s0 + u < nslab ? src[(size_t)(s0 + u) * stride4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v.x += a[u].x; v.y += a[u].y; v.z += a[u].z; v.w += a[u].w; }
+        }
         out[i] = v;
     }
 }
 
 // ---- host side -------------------------------------------------------------------------
-static void clip_plan(int Br, int Bg, int* nsplit, int* tiles_per_split) {
+// Which kernels and how many column splits.  Tall row blocks (one rank of a large batch) take the tiled kernels of
+// clip_tiled.hip: 128 rows per workgroup, about 512 workgroups, at least four column tiles each.
+struct ClipPlan { int nsplit, tiles_per_split, npart; bool tiled; };
+static ClipPlan clip_plan(int Br, int Bg, bool backward) {
+    ClipPlan pl;
     const int nct = (Bg + 31) / 32;
+    pl.tiled = Br >= CLIP_TILED_MIN_ROWS;
+    if (pl.tiled) {
+        const int rowblocks = (Br + 127) / 128;
+        // two workgroups per CU (measured at 1024 x 8192: 256 and 1024 workgroups are 4-7 % and 8-40 % slower)
+        int ns = 512 / (2 * rowblocks);
+        if (ns > nct / 4) ns = nct / 4;
+        if (ns > 64) ns = 64;
+        if (ns < 1) ns = 1;
+        pl.tiles_per_split = (nct + ns - 1) / ns;
+        pl.nsplit = (nct + pl.tiles_per_split - 1) / pl.tiles_per_split;
+        pl.npart = pl.nsplit;
+        return pl;
+    }
     const int rowtiles = (Br + 31) / 32;
     int ns = (nct + 3) / 4;                       // at least one tile per wave
     int cap = 1024 / (rowtiles * 2);              // about 4 blocks per CU at most
@@ -237,13 +261,16 @@ static void clip_plan(int Br, int Bg, int* nsplit, int* tiles_per_split) {
     if (ns > 64) ns = 64;
     int tps = (nct + ns - 1) / ns;
     tps = (tps + 3) / 4 * 4;
-    ns = (nct + tps - 1) / tps;
-    *nsplit = ns;
-    *tiles_per_split = tps;
+    pl.tiles_per_split = tps;
+    pl.nsplit = (nct + tps - 1) / tps;
+    pl.npart = pl.nsplit * 4;
+    return pl;
 }
 
-static size_t clip_fwd_ws(int Br, int nsplit) {  // part[2][npart][Br] float2 + diag[2][Br]
-    return pclip_align_up((size_t)2 * nsplit * 4 * Br * sizeof(float2), 256) + pclip_align_up((size_t)2 * Br * sizeof(float), 256);
+static int clip_fin_blocks(int Br) { return (2 * Br + CLIP_FIN_THREADS - 1) / CLIP_FIN_THREADS; }
+static size_t clip_fwd_ws(int Br, int npart) {  // part[2][npart][Br] float2 | diag[2][Br] | ticket | partial losses of the finalize blocks
+    return pclip_align_up((size_t)2 * npart * Br * sizeof(float2), 256) + pclip_align_up((size_t)2 * Br * sizeof(float), 256) + 256 +
+           pclip_align_up((size_t)clip_fin_blocks(Br) * sizeof(float), 256);
 }
 static size_t clip_bwd_ws(int Br, int d, int nsplit) {  // slab[2][nsplit][Br][d]
     return pclip_align_up((size_t)2 * nsplit * Br * d * sizeof(float), 256);
@@ -251,9 +278,7 @@ static size_t clip_bwd_ws(int Br, int d, int nsplit) {  // slab[2][nsplit][Br][d
 
 extern "C" size_t pclip_clip_workspace_bytes(int Br, int Bg, int d) {
     if (Br < 1 || Bg < 1 || d < 1) return 0;
-    int ns, tps;
-    clip_plan(Br, Bg, &ns, &tps);
-    size_t a = clip_fwd_ws(Br, ns), b = clip_bwd_ws(Br, d, ns);
+    size_t a = clip_fwd_ws(Br, clip_plan(Br, Bg, false).npart), b = clip_bwd_ws(Br, d, clip_plan(Br, Bg, true).nsplit);
     return a > b ? a : b;
 }
 
@@ -273,20 +298,27 @@ extern "C" int pclip_clip_fwd(const float* X_own, const float* Y_own, const floa
     PCLIP_REQUIRE(((uintptr_t)X_own | (uintptr_t)Y_own | (uintptr_t)X_all | (uintptr_t)Y_all) % 16 == 0,
                   "clip_fwd: operand pointers must be 16-byte aligned");
     ClipArgs a = {};
-    clip_plan(Br, Bg, &a.nsplit, &a.tiles_per_split);
-    PCLIP_REQUIRE(ws_bytes >= clip_fwd_ws(Br, a.nsplit), "clip_fwd: workspace %zu < %zu bytes", ws_bytes, clip_fwd_ws(Br, a.nsplit));
-    const int npart = a.nsplit * 4;
+    const ClipPlan pl = clip_plan(Br, Bg, false);
+    a.nsplit = pl.nsplit; a.tiles_per_split = pl.tiles_per_split; a.npart = pl.npart;
+    PCLIP_REQUIRE(ws_bytes >= clip_fwd_ws(Br, a.npart), "clip_fwd: workspace %zu < %zu bytes", ws_bytes, clip_fwd_ws(Br, a.npart));
+    const int npart = a.npart;
     float2* part = (float2*)ws;
     float* diag = (float*)((char*)ws + pclip_align_up((size_t)2 * npart * Br * sizeof(float2), 256));
+    a.fin_counter = (unsigned*)((char*)diag + pclip_align_up((size_t)2 * Br * sizeof(float), 256));
+    a.fin_part = (float*)((char*)a.fin_counter + 256);
     a.d = d;
     a.logits_mode = logits_out ? logits_mode : 0;
     a.scale = 0.5f / (float)Bg;
     a.p[0] = ClipProb{X_own, Y_all, Br, Bg, row_offset, part, diag, lse_row, a.logits_mode ? logits_out : nullptr, nullptr, nullptr, nullptr};
     a.p[1] = ClipProb{Y_own, X_all, Br, Bg, row_offset, part + (size_t)npart * Br, diag + Br, lse_col, nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(clip_lse_kernel, dim3((Br + 31) / 32, a.nsplit, 2), dim3(256), 0, st, a);
-    if (int rc = pclip_check_launch("clip_lse_kernel")) return rc;
-    hipLaunchKernelGGL(clip_finalize_kernel, dim3(1), dim3(1024), 0, st, a, loss_part);
+    if (pl.tiled) {
+        if (int rc = clip_lse_tiled_launch(a, Br, st)) return rc;
+    } else {
+        hipLaunchKernelGGL(clip_lse_kernel, dim3((Br + 31) / 32, a.nsplit, 2), dim3(256), 0, st, a);
+        if (int rc = pclip_check_launch("clip_lse_kernel")) return rc;
+    }
+    hipLaunchKernelGGL(clip_finalize_kernel, dim3(clip_fin_blocks(Br)), dim3(CLIP_FIN_THREADS), 0, st, a, loss_part);
     return pclip_check_launch("clip_finalize_kernel");
 }
 
@@ -295,7 +327,8 @@ static int clip_grad_launch(const float* X_own, const float* Y_own, const float*
                             const float* lse_col_all, int Br, int Bg, int d, int row_offset, const float* g, float* slab,
                             int* nsplit_out, hipStream_t st) {
     ClipArgs a = {};
-    clip_plan(Br, Bg, &a.nsplit, &a.tiles_per_split);
+    const ClipPlan pl = clip_plan(Br, Bg, true);
+    a.nsplit = pl.nsplit; a.tiles_per_split = pl.tiles_per_split; a.npart = pl.npart;
     a.d = d;
     a.scale = 0.5f / (float)Bg;
     a.g = g;
@@ -303,6 +336,7 @@ static int clip_grad_launch(const float* X_own, const float* Y_own, const float*
     a.p[1] = ClipProb{Y_own, X_all, Br, Bg, row_offset, nullptr, nullptr, nullptr, nullptr, lse_col_all + row_offset, lse_row_all,
                       slab + (size_t)a.nsplit * Br * d};
     *nsplit_out = a.nsplit;
+    if (pl.tiled) return clip_grad_tiled_launch(a, Br, st);
     static PclipLdsLimit lds_limit;  // 66 KB of dynamic LDS is above the default launch limit
     if (int rc = pclip_ensure_lds(lds_limit, (const void*)clip_grad_kernel, 4 * 32 * 129 * sizeof(float), "clip_grad_kernel")) return rc;
     hipLaunchKernelGGL(clip_grad_kernel, dim3((Br + 31) / 32, a.nsplit, 2), dim3(256), 4 * 32 * 129 * sizeof(float), st, a);
@@ -314,16 +348,16 @@ extern "C" int pclip_clip_bwd(const float* X_own, const float* Y_own, const floa
                               float* dY_own, void* ws, size_t ws_bytes, void* stream) {
     PCLIP_REQUIRE(X_own && Y_own && X_all && Y_all && lse_row_all && lse_col_all && dX_own && dY_own && ws, "clip_bwd: null pointer");
     if (int rc = clip_check("clip_bwd", Br, Bg, d, row_offset)) return rc;
-    int ns, tps;
-    clip_plan(Br, Bg, &ns, &tps);
+    PCLIP_REQUIRE(((uintptr_t)X_own | (uintptr_t)Y_own | (uintptr_t)X_all | (uintptr_t)Y_all | (uintptr_t)dX_own | (uintptr_t)dY_own | (uintptr_t)ws) % 16 == 0,
+                  "clip_bwd: operand pointers must be 16-byte aligned");
+    int ns = clip_plan(Br, Bg, true).nsplit;
     PCLIP_REQUIRE(ws_bytes >= clip_bwd_ws(Br, d, ns), "clip_bwd: workspace %zu < %zu bytes", ws_bytes, clip_bwd_ws(Br, d, ns));
     hipStream_t st = (hipStream_t)stream;
     float* slab = (float*)ws;
     if (int rc = clip_grad_launch(X_own, Y_own, X_all, Y_all, lse_row_all, lse_col_all, Br, Bg, d, row_offset, g, slab, &ns, st)) return rc;
-    const size_t n = (size_t)Br * d;
-    const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, st, slab, ns, n, dX_own, n);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, st, slab + (size_t)ns * n, ns, n, dY_own, n);
+    const size_t n4 = (size_t)Br * d / 4;   // d is a multiple of 4
+    const int blocks = (int)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks, 2), dim3(256), 0, st, (const float4*)slab, ns, n4, (float4*)dX_own, (float4*)dY_own, n4);
     return pclip_check_launch("slab_sum_kernel");
 }
 

@@ -52,6 +52,35 @@ def test_clip_rank_shape_1024_of_8192(K):
     assert 0 < total < float(torch.log(torch.tensor(float(Bg))))   # three of eight shares of a loss below ln B
 
 
+@pytest.mark.parametrize("Br,Bg,off,d", [(130, 130, 0, 128), (200, 470, 100, 96), (129, 257, 128, 64), (384, 1000, 616, 128), (512, 513, 1, 4)])
+def test_clip_tall_row_blocks_with_ragged_edges(K, Br, Bg, off, d):
+    """The kernels that take 128 own rows per workgroup (Br >= 128), at sizes that are no multiple of any
+    tile, widths below 128 and own rows at the very end of the batch: log-sum-exps, loss share, the logits in
+    both output modes and dX / dY against float64."""
+    gen = torch.Generator().manual_seed(Br + Bg)
+    x32 = O.l2norm_scale(torch.randn(Bg, d, generator=gen), torch.tensor(1.3)).cuda()
+    y32 = O.l2norm_scale(torch.randn(Bg, d, generator=gen), torch.tensor(1.3)).cuda()
+    x, y = x32.double(), y32.double()
+    S = x @ y.t()
+    lse_r, lse_c = torch.logsumexp(S, 1), torch.logsumexp(S, 0)
+    G = (0.5 / Bg) * (torch.softmax(S, 1) + torch.softmax(S, 0) - 2 * torch.eye(Bg, dtype=torch.float64, device="cuda"))
+    sl = slice(off, off + Br)
+    xo, yo = x32[sl].contiguous(), y32[sl].contiguous()
+    for mode in (0, 1, 2):
+        got_r, got_c, part, logits = K.clip_fwd(xo, yo, x32, y32, off, logits_mode=mode)
+        torch.testing.assert_close(got_r.double(), lse_r[sl], rtol=1e-6, atol=2e-6)
+        torch.testing.assert_close(got_c.double(), lse_c[sl], rtol=1e-6, atol=2e-6)
+        want_part = (0.5 / Bg) * (lse_r[sl] + lse_c[sl] - 2 * torch.diagonal(S)[sl]).sum()
+        torch.testing.assert_close(part.double().reshape(()), want_part, rtol=1e-5, atol=1e-7)
+        if mode == 1:
+            torch.testing.assert_close(logits.double(), S[sl], rtol=1e-6, atol=2e-6)
+        if mode == 2:
+            torch.testing.assert_close(logits.double(), S[sl].exp(), rtol=1e-5, atol=1e-6)
+    dX, dY = K.clip_bwd(xo, yo, x32, y32, lse_r.float().contiguous(), lse_c.float().contiguous(), off)
+    torch.testing.assert_close(dX.double(), (G @ y)[sl], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(dY.double(), (G.t() @ x)[sl], rtol=1e-4, atol=1e-8)
+
+
 def test_filip_rank_shape_256_by_2048(K):
     """Scores of sampled row / column blocks against the oracle (a pair's scores depend on that
     pair alone), every chosen partner attains its maximum, the backward equals the routed sum for

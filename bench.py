@@ -168,6 +168,38 @@ def rank_shape_records(K, device):
     return out
 
 
+def head_record(K, device):
+    """The step in front of the hot path: masked mean over tokens and the embedding head of one CLIP tower
+    (Linear -> ReLU -> LayerNorm -> Dropout -> Linear -> normalise, scale), forward and backward kernels
+    alone at B = 256, T = 256, d = 128."""
+    B, T = 256, 256
+    g = torch.Generator().manual_seed(5)
+    h = torch.randn(B, T, D, generator=g).to(device)
+    mask = (torch.arange(T)[None] < torch.randint(128, T + 1, (B, 1), generator=g)).to(torch.uint8).to(device)
+    params = [(torch.randn(D, D, generator=g) / D ** 0.5).to(device), torch.zeros(D, device=device), torch.ones(D, device=device),
+              torch.zeros(D, device=device), (torch.randn(D, D, generator=g) / D ** 0.5).to(device), torch.zeros(D, device=device)]
+    keep = (torch.rand(1, B, D, generator=g) >= 0.1).to(torch.uint8).to(device)
+    t = torch.tensor([1.0], device=device)
+    w = torch.randn(B, D, generator=g).to(device)
+    st = {}
+
+    def fwd():
+        st["pool"] = K.masked_mean_fwd(h, mask)
+        st["out"] = K.head_tail_fwd(st["pool"][0], params, keep, 1.0 / 0.9, 1e-5, t)
+
+    def bwd():
+        pooled, inv, m8 = st["pool"]
+        d_pooled, _, _ = K.head_tail_bwd(pooled, params, keep, 1.0 / 0.9, 1e-5, t, st["out"][1], w)
+        K.masked_mean_bwd(d_pooled, m8, inv, T)
+    ms_f = _median_ms(fwd, 30)
+    ms_b = _median_ms(bwd, 30)
+    byts = 2.0 * B * T * D * 4   # the token tensor read once forward, its gradient written once backward
+    return {"embedding_head_b256_t256": {
+        "note": "masked mean + embedding head of one CLIP tower, kernels only (host wrappers included); not part of `value`",
+        "fwd_ms": ms_f, "bwd_ms": ms_b, "algorithmic_bytes": byts, "hbm_GBs": byts / ((ms_f + ms_b) * 1e-3) / 1e9,
+        "hbm_frac": byts / ((ms_f + ms_b) * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -336,6 +368,7 @@ def main():
                 }
         if not multi and not args.no_rank_shapes and args.workload == "both":
             workloads.update(rank_shape_records(K, device))
+            workloads.update(head_record(K, device))
         out = {
             "metric": "protein_pairs_per_sec", "value": pairs / (total / args.steps), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": SETTLE_STEPS, "ms_per_step": total / args.steps * 1e3,

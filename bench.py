@@ -202,6 +202,12 @@ def head_record(K, device):
 
 def main():
     args = parse()
+    # Libraries below this script write to file descriptor 1 on their own (RCCL prints a version banner there when
+    # a process group is created).  The contract is ONE JSON line on stdout, so everything else is sent to stderr
+    # and the line is written to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -387,7 +393,8 @@ def main():
             out["note"] = "rehearsal of the multi-rank code on one GPU (--rehearse-dist); not a benchmark result"
         if not multi and not args.no_cpu_baseline and args.workload == "both":
             out["cpu_baseline"] = cpu_baseline(cpu, clip_bl, filip_bl)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if multi:
         dist.destroy_process_group()
 

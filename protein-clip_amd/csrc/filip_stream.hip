@@ -105,10 +105,19 @@ __device__ __forceinline__ float row16_sum(float v) {
 #undef DPP_ADD
     return v;
 }
+// the value of lane l ^ 16 / l ^ 32, through the gfx950 swap instructions (no LDS round trip)
+__device__ __forceinline__ int xor16_i(int v, int lane) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (lane & 16) ? (int)r[0] : (int)r[1];
+}
+__device__ __forceinline__ int xor32_i(int v, int lane) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (lane & 32) ? (int)r[0] : (int)r[1];
+}
 // sum over each 32-lane half, result in every lane of the half
-__device__ __forceinline__ float half32_sum(float v) {
+__device__ __forceinline__ float half32_sum(float v, int lane) {
     v = row16_sum(v);
-    return v + __shfl_xor(v, 16);
+    return v + __int_as_float(xor16_i(__float_as_int(v), lane));
 }
 
 // One finished accumulator tile -> its 16 keys per lane, in place of the accumulator:
@@ -350,6 +359,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         for (int k = 0; k < SE / 2; ++k) g[k] = (uint32_t)__builtin_amdgcn_readlane((int)rec.y, base_lane + dq + 2 * k);
     };
 
+    uint16_t* const arg_base = p.argA ? p.argA + ((size_t)max(ISEQ(slot_isel), 0) * p.Bc + j_begin) * p.TAp : nullptr;
     int KM[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) KM[r] = NEG_KEY;
@@ -514,7 +524,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 int cc;
                 {
                     // the other half's best; on equal keys the lower half (the lower columns) wins
-                    const int om = __shfl_xor(m, 32);
+                    const int om = xor32_i(m, lane);
                     const bool take = om + h > m;
                     m = take ? om : m;
                     cc = 15 - (m & 15) + 16 * (take ? 1 - h : h);
@@ -523,10 +533,10 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 const bool valid = (wA >> c) & 1u;
                 const bool none = m < 0;
                 const float val = none ? -FLT_MAX : key_value(m);
-                const float rs = half32_sum(valid ? val : 0.f);
+                const float rs = half32_sum(valid ? val : 0.f, lane);
                 if (lane == 0) rowp[(par3 * SE + q) * 16 + slot_isel * 8 + slot_at] = rs;
-                if (h == 0 && p.argA)
-                    p.argA[((size_t)ISEQ(slot_isel) * p.Bc + j_begin + (int)(mz & 0xff)) * p.TAp + slot_at * 32 + c] =
+                if (h == 0 && p.argA)   // scalar base of this wave's A sequence and B chunk, 32-bit lane offset
+                    arg_base[(uint32_t)((int)(mz & 0xff) * p.TAp + slot_at * 32 + c)] =
                         (none || !valid) ? (uint16_t)0 : (uint16_t)(((m >> 4) & 7) * 32 + cc);
                 STAMP(4);
             }
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                     if (p.argB)
                         p.argB[((size_t)ISEQ(isel) * p.Bc + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = (uint16_t)barg;
                 }
-                const float cs = half32_sum(cv);
+                const float cs = half32_sum(cv, lane);
                 if (c == 0) colpart[(par3 * SE + q) * 2 + isel] = cs;
             }
         }

@@ -99,7 +99,10 @@ int pclip_clip_bwd(const float* X_own, const float* Y_own, const float* X_all, c
 
 /* One-GPU fused step from raw head outputs (models.py:50-51 on both towers, then
  * training_utils.py:85-89, then loss.backward()): writes loss, d e_pep, d e_rec and dt
- * (dt is overwritten here). */
+ * (dt is overwritten here).  Up to B = 512 the step is ONE persistent launch whose workgroups
+ * meet at grid-wide barriers; that form is only taken when the CURRENT device keeps the whole grid
+ * resident (a partition with few compute units takes the separate launches instead), so size the
+ * workspace with the device current on which the step will run. */
 size_t pclip_clip_step_workspace_bytes(int B, int d);
 int pclip_clip_step(const float* e_pep, const float* e_rec, const float* t, int B, int d,
                     float* loss, float* de_pep, float* de_rec, float* dt,

@@ -349,7 +349,33 @@ __global__ __launch_bounds__(256) void clip_step_kernel(ClipStepArgs p) {
 }
 
 // ---- host side -------------------------------------------------------------------------
-bool clip_step_fused_ok(int B, int d) { return B >= 1 && B <= 32 * CS_MAXT && d >= 4 && d <= CS_D && d % 4 == 0; }
+#define CS_LDS_BYTES ((size_t)(3 * 32 * CS_LD + 32 * 33 + 64) * sizeof(float))
+
+// Workgroups of this kernel that the current device keeps resident at once (the grid barrier needs the whole
+// grid resident: a device partition with few CUs takes the separate launches instead).  Asked once per device.
+static int clip_step_resident_capacity() {
+    static std::mutex mu;
+    static int cap[PCLIP_MAX_DEVICES];
+    static PclipLdsLimit lim;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PCLIP_MAX_DEVICES) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cap[dev] == 0) {
+        int cus = 0, per_cu = 0;
+        cap[dev] = -1;
+        if (pclip_ensure_lds(lim, (const void*)clip_step_kernel, CS_LDS_BYTES, "clip_step_kernel") == PCLIP_OK &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)clip_step_kernel, 256, CS_LDS_BYTES) == hipSuccess && cus * per_cu > 0)
+            cap[dev] = cus * per_cu;
+    }
+    return cap[dev] > 0 ? cap[dev] : 0;
+}
+
+bool clip_step_fused_ok(int B, int d) {
+    if (!(B >= 1 && B <= 32 * CS_MAXT && d >= 4 && d <= CS_D && d % 4 == 0)) return false;
+    const int nT = (B + 31) / 32;
+    return nT * nT <= clip_step_resident_capacity();
+}
 
 struct ClipStepWs { size_t counter, part_row, part_col, diag, lse_row, lse_col, slab_x, slab_y, total; };
 static ClipStepWs clip_step_layout(int B, int d) {
@@ -382,9 +408,6 @@ int clip_step_fused_launch(const float* e_pep, const float* e_rec, const float* 
     a.slab_x = (float*)(w + L.slab_x); a.slab_y = (float*)(w + L.slab_y);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(a.counter, 0, 256, st) != hipSuccess) return pclip_fail(PCLIP_ELAUNCH, "clip_step: cannot clear the barrier counter");
-    const size_t lds = (size_t)(3 * 32 * CS_LD + 32 * 33 + 64) * sizeof(float);
-    static PclipLdsLimit lim;
-    if (int rc = pclip_ensure_lds(lim, (const void*)clip_step_kernel, lds, "clip_step_kernel")) return rc;
-    hipLaunchKernelGGL(clip_step_kernel, dim3(a.nT * a.nT), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(clip_step_kernel, dim3(a.nT * a.nT), dim3(256), CS_LDS_BYTES, st, a);   // the LDS limit was raised by the capacity query
     return pclip_check_launch("clip_step_kernel");
 }

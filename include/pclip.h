@@ -108,6 +108,14 @@ int pclip_clip_step(const float* e_pep, const float* e_rec, const float* t, int 
                     float* loss, float* de_pep, float* de_rec, float* dt,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* Loss and both gradients from the towers' OUTPUTS on one GPU (training_utils.py:85-89 followed by
+ * loss.backward(), for x, y [B,d] as Encoder.forward returns them): loss (device scalar),
+ * dx, dy [B,d] = d loss / d x, d loss / d y, all overwritten.  One launch up to B = 512 (see
+ * pclip_clip_step), the forward and backward launches beyond. */
+size_t pclip_clip_loss_grad_workspace_bytes(int B, int d);
+int pclip_clip_loss_grad(const float* x, const float* y, int B, int d, float* loss, float* dx, float* dy,
+                         void* ws, size_t ws_bytes, void* stream);
+
 /* The same step without a workspace argument.  It has no counterpart in the reference: it exists
  * for callers that cannot allocate device memory or size a workspace (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  The scratch of the step lives in

@@ -401,6 +401,31 @@ extern "C" int pclip_clip_step(const float* e_pep, const float* e_rec, const flo
     return l2norm_scale_bwd_pair_launch(e_pep, e_rec, t, slab, slab + (size_t)ns * n, ns, n, de_pep, de_rec, dt, B, d, stream);
 }
 
+// ---- loss and both gradients from the towers' outputs, one GPU ---------------------------
+// B <= 512 on a device that keeps the grid resident: the one persistent launch, without its normalise stages.
+// Otherwise the forward and backward launches; workspace: lse_row, lse_col [B] | their scratch.
+extern "C" size_t pclip_clip_loss_grad_workspace_bytes(int B, int d) {
+    if (B < 1 || d < 1) return 0;
+    if (clip_step_fused_ok(B, d)) return clip_step_fused_ws_bytes(B, d);
+    return pclip_align_up((size_t)2 * B * sizeof(float), 256) + pclip_clip_workspace_bytes(B, B, d);
+}
+
+extern "C" int pclip_clip_loss_grad(const float* x, const float* y, int B, int d, float* loss, float* dx, float* dy, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    PCLIP_REQUIRE(x && y && loss && dx && dy && ws, "clip_loss_grad: null pointer");
+    if (int rc = clip_check("clip_loss_grad", B, B, d, 0)) return rc;
+    PCLIP_REQUIRE(ws_bytes >= pclip_clip_loss_grad_workspace_bytes(B, d), "clip_loss_grad: workspace %zu < %zu bytes", ws_bytes,
+                  pclip_clip_loss_grad_workspace_bytes(B, d));
+    PCLIP_REQUIRE(((uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)dy | (uintptr_t)ws) % 16 == 0, "clip_loss_grad: pointers must be 16-byte aligned");
+    if (clip_step_fused_ok(B, d)) return clip_step_fused_launch(x, y, nullptr, B, d, loss, dx, dy, nullptr, ws, stream);
+    float* lse_row = (float*)ws;
+    float* lse_col = lse_row + B;
+    void* cws = (char*)ws + pclip_align_up((size_t)2 * B * sizeof(float), 256);
+    const size_t cws_bytes = pclip_clip_workspace_bytes(B, B, d);
+    if (int rc = pclip_clip_fwd(x, y, x, y, B, B, d, 0, lse_row, lse_col, loss, nullptr, 0, cws, cws_bytes, stream)) return rc;
+    return pclip_clip_bwd(x, y, x, y, lse_row, lse_col, B, B, d, 0, nullptr, dx, dy, cws, cws_bytes, stream);
+}
+
 // ---- the same step for callers that cannot allocate --------------------------------------
 // The workspace of pclip_clip_step lives in a device array of this code object: every GPU the
 // library runs on holds its own copy at its own address until the process ends.  Host code never

@@ -30,6 +30,7 @@ struct ClipStepArgs {
     const float* e_pep; const float* e_rec; const float* t;
     float* loss; float* de_pep; float* de_rec; float* dt;
     int B, d, nT;
+    int raw;                  // 1: e_pep / e_rec are raw head outputs (normalise, scale, Jacobian, dt); 0: they are x, y as the towers return them
     float scale;              // 0.5 / B
     unsigned* counter;        // [0] arrivals (zeroed by the launcher), [1] set when a wait gave up
     float2* part_row;         // [nT (tile column)][B]  (max, sum) of row i over the tile's 32 columns
@@ -85,7 +86,7 @@ __device__ __forceinline__ float sum16(float v) {
 // held by 16 lanes (columns 4 l .. 4 l + 3 and 64 + 4 l .. 64 + 4 l + 3 of lane l), four rows per
 // pass: four passes, all eight loads issued before the first reduction (one memory latency).
 __device__ __forceinline__ void stage_rows(const float* __restrict__ e0, int r0, float* tile0, const float* __restrict__ e1, int r1, float* tile1,
-                                           int B, int d, float s, int w, int lane) {
+                                           int B, int d, float s, bool raw, int w, int lane) {
     const int l = lane & 15, g = lane >> 4;
     float4 v[8];
 #pragma unroll
@@ -99,7 +100,7 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ e0, int r0,
     for (int u = 0; u < 8; u += 2) {
         const float4 a = v[u], b = v[u + 1];
         const float ss = sum16(((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w)) + ((b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w)));
-        const float f = s / fmaxf(sqrtf(ss), 1e-12f);
+        const float f = raw ? s / fmaxf(sqrtf(ss), 1e-12f) : 1.f;
         float* o = ((u >> 2) ? tile1 : tile0) + (8 * w + 4 * ((u >> 1) & 1) + g) * CS_LD + 4 * l;
         o[0] = a.x * f; o[1] = a.y * f; o[2] = a.z * f; o[3] = a.w * f;
         o[64] = b.x * f; o[65] = b.y * f; o[66] = b.z * f; o[67] = b.w * f;
@@ -131,12 +132,13 @@ __global__ __launch_bounds__(256) void clip_step_kernel(ClipStepArgs p) {
     const int B = p.B, d = p.d;
     const unsigned nwg = gridDim.x;
 
-    if (blockIdx.x == 0 && tid == 0) st_f32(p.dt, 0.f);   // phase C adds into it, two barriers from here
+    if (blockIdx.x == 0 && tid == 0 && p.raw) st_f32(p.dt, 0.f);   // phase C adds into it, two barriers from here
 
     // ---- phase A --------------------------------------------------------------------------
     CSTAMP(0);
-    const float s = expf(p.t[0] * 0.5f);
-    stage_rows(p.e_pep, i0, xs, p.e_rec, j0, ys, B, d, s, w, lane);
+    const bool raw = p.raw != 0;
+    const float s = raw ? expf(p.t[0] * 0.5f) : 1.f;
+    stage_rows(p.e_pep, i0, xs, p.e_rec, j0, ys, B, d, s, raw, w, lane);
     __syncthreads();
     CSTAMP(1);
     f32x16 T = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -312,7 +314,9 @@ __global__ __launch_bounds__(256) void clip_step_kernel(ClipStepArgs p) {
             const float dot = sum16(((v0.x * a0.x + v0.y * a0.y) + (v0.z * a0.z + v0.w * a0.w)) + ((v1.x * a1.x + v1.y * a1.y) + (v1.z * a1.z + v1.w * a1.w)));   // e . dx
             const float nrm = sqrtf(ss);
             float f, gcoef;   // d e = f * (dx - gcoef * e)
-            if (nrm >= 1e-12f) {
+            if (!raw) {   // the inputs are the normalised rows themselves
+                f = 1.f; gcoef = 0.f;
+            } else if (nrm >= 1e-12f) {
                 const float inv = 1.f / nrm, ndx = dot * inv;   // n . dx
                 f = s * inv; gcoef = inv * ndx;
                 if (l == 0) dts += 0.5f * s * ndx;
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(256) void clip_step_kernel(ClipStepArgs p) {
         __syncthreads();
         if (tid == 0) {
             const float v = (dtp[0] + dtp[1]) + (dtp[2] + dtp[3]);
-            if (v != 0.f) atomicAdd(p.dt, v);
+            if (raw && v != 0.f) atomicAdd(p.dt, v);
         }
     }
     CSTAMP(8);
@@ -395,13 +399,14 @@ static ClipStepWs clip_step_layout(int B, int d) {
 }
 size_t clip_step_fused_ws_bytes(int B, int d) { return clip_step_layout(B, d).total; }
 
+// t == NULL: e_pep / e_rec are x, y as the towers return them (no normalise, no temperature; dt is not touched)
 int clip_step_fused_launch(const float* e_pep, const float* e_rec, const float* t, int B, int d, float* loss, float* de_pep, float* de_rec,
                            float* dt, void* ws, void* stream) {
     const ClipStepWs L = clip_step_layout(B, d);
     char* w = (char*)ws;
     ClipStepArgs a;
     a.e_pep = e_pep; a.e_rec = e_rec; a.t = t; a.loss = loss; a.de_pep = de_pep; a.de_rec = de_rec; a.dt = dt;
-    a.B = B; a.d = d; a.nT = (B + 31) / 32; a.scale = 0.5f / (float)B;
+    a.B = B; a.d = d; a.nT = (B + 31) / 32; a.scale = 0.5f / (float)B; a.raw = t != nullptr;
     a.counter = (unsigned*)(w + L.counter);
     a.part_row = (float2*)(w + L.part_row); a.part_col = (float2*)(w + L.part_col);
     a.diag = (float*)(w + L.diag); a.lse_row = (float*)(w + L.lse_row); a.lse_col = (float*)(w + L.lse_col);

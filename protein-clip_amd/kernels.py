@@ -208,6 +208,22 @@ def clip_bwd(X_own, Y_own, X_all, Y_all, lse_row_all, lse_col_all, row_offset: i
     return dX, dY
 
 
+def clip_loss_grad(x, y):
+    """x, y [B,d] as the towers return them -> (loss [1], d loss / d x, d loss / d y): the loss of
+    training_utils.py:85-89 and its backward in one call (one launch up to B = 512)."""
+    require_gpu_tensor(x, F32, "x")
+    require_gpu_tensor(y, F32, "y")
+    if x.shape != y.shape or x.dim() != 2:
+        raise _lib.PclipError("clip_loss_grad: expected two [B,d] tensors of one shape")
+    B, d = x.shape
+    lib = _lib.load()
+    ws = _workspace(x.device, lib.pclip_clip_loss_grad_workspace_bytes(B, d))
+    loss = torch.empty(1, dtype=F32, device=x.device)
+    dx, dy = torch.empty_like(x), torch.empty_like(y)
+    check(lib.pclip_clip_loss_grad(ptr(x), ptr(y), B, d, ptr(loss), ptr(dx), ptr(dy), ptr(ws), ws.numel(), stream_of(x)), "pclip_clip_loss_grad")
+    return loss, dx, dy
+
+
 class ClipStep:
     """Pre-allocated fused step (normalise both towers -> loss -> all gradients) for one
     (B, d): every buffer is created once, ``run`` only enqueues kernels."""

@@ -149,6 +149,14 @@ class _ClipLoss(torch.autograd.Function):
         x = x.contiguous()
         y = y.contiguous()
         Bl = x.shape[0]
+        ctx.fused = False
+        if not _collective(world) and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and hasattr(K, "clip_loss_grad"):
+            # one process, gradients wanted: loss and both gradients come out of one call (one launch up to
+            # B = 512); the backward only scales them by the upstream gradient
+            loss, dx, dy = K.clip_loss_grad(x, y)
+            ctx.fused = True
+            ctx.save_for_backward(dx, dy)
+            return loss.reshape(())
         x_all = _all_gather_rows(x, group, world)
         y_all = _all_gather_rows(y, group, world)
         off = rank * Bl
@@ -168,6 +176,9 @@ class _ClipLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.fused:
+            dx, dy = ctx.saved_tensors
+            return dx * g, dy * g, None, None
         x, y, x_all, y_all, lse_r_all, lse_c_all = ctx.saved_tensors
         dX, dY = ctx.K.clip_bwd(x, y, x_all, y_all, lse_r_all, lse_c_all, ctx.off, g=g.reshape(1))
         return dX, dY, None, None

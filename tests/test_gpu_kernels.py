@@ -43,6 +43,30 @@ def mostly_close(a, b, rtol, atol, max_bad_frac=0.0, max_rel_l2=None):
         assert rel <= max_rel_l2, f"relative L2 error {rel:.3e} > {max_rel_l2:.1e}"
 
 
+def test_clip_loss_grad_from_tower_outputs(K, clip_cases):
+    """pclip_clip_loss_grad (loss and both gradients from x, y as the towers return them) against the
+    reference's loss and autograd on the golden cases, and against the forward + backward entry points at
+    sizes on both sides of the one-launch limit."""
+    for key, c in clip_cases.items():
+        x = c["x"].clone().requires_grad_(True)
+        y = c["y"].clone().requires_grad_(True)
+        O.clip_contrastive_loss(x, y.t()).backward()
+        loss, dx, dy = K.clip_loss_grad(dev(c["x"]), dev(c["y"]))
+        close(loss, c["loss"].reshape(1), 1e-5, 1e-6)
+        close(dx, x.grad, 1e-4, 1e-7)
+        close(dy, y.grad, 1e-4, 1e-7)
+    g = torch.Generator().manual_seed(11)
+    for B, d in [(256, 128), (512, 128), (544, 128), (100, 64)]:
+        x = dev(O.l2norm_scale(torch.randn(B, d, generator=g), torch.tensor(1.0)))
+        y = dev(O.l2norm_scale(torch.randn(B, d, generator=g), torch.tensor(1.0)))
+        loss, dx, dy = K.clip_loss_grad(x, y)
+        lr, lc, want_loss, _ = K.clip_fwd(x, y, x, y, 0)
+        want_dx, want_dy = K.clip_bwd(x, y, x, y, lr, lc, 0)
+        torch.testing.assert_close(loss, want_loss, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(dx, want_dx, rtol=1e-4, atol=1e-9)
+        torch.testing.assert_close(dy, want_dy, rtol=1e-4, atol=1e-9)
+
+
 # ------------------------------------------------------------------------------------------
 # embedding head: pooling -> Linear/ReLU/LayerNorm/Dropout blocks -> Linear -> normalise, scale
 # ------------------------------------------------------------------------------------------

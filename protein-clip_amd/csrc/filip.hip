@@ -13,7 +13,8 @@
 #define ROWB (FD * 2)     // bytes per token row
 
 // ---- prep: f32 [B,T,d] -> bf16 [B,Tp,128] (+ mask words) --------------------------------
-// One block per 32-token tile of one sequence; wave w converts tokens w, w+4, ...
+// One block per 32-token tile of one sequence: eight lanes per token (widths that are a multiple of four), or
+// wave w converts tokens w, w+4, ...
 __global__ __launch_bounds__(256) void filip_prep_kernel(const float* __restrict__ h, const uint8_t* __restrict__ mask, int B, int T, int d,
                                                          int Tp, int normalise, const float* __restrict__ tsign,
                                                          uint16_t* __restrict__ hn, uint32_t* __restrict__ maskw) {
@@ -26,6 +27,48 @@ __global__ __launch_bounds__(256) void filip_prep_kernel(const float* __restrict
         const bool on = lane < 32 && tok < T && mask[(size_t)seq * T + tok] != 0;
         const unsigned long long bal = __ballot(on);
         if (lane == 0) maskw[(size_t)seq * ntile + tile] = (uint32_t)bal;
+    }
+    if ((d & 3) == 0 && ((uintptr_t)h & 15) == 0) {
+        // eight lanes per token, sixteen columns each: the whole tile in one pass, four 16-byte loads per thread in flight
+        const int r = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+        const int tok = tile * 32 + r;
+        // the row is requested together with its mask byte (no load waits for another); a masked row is dropped afterwards
+        const uint8_t mbyte = tok < T ? mask[(size_t)seq * T + tok] : (uint8_t)0;
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 16 * l8 + 4 * u;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tok < T && k < d) v[u] = *reinterpret_cast<const float4*>(h + ((size_t)seq * T + tok) * d + k);
+        }
+        const bool live = mbyte != 0;
+        if (!live) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (normalise) {
+            float ss = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ss += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+            const float nrm = sqrtf(ss);
+            if (live) {   // no epsilon, as in the reference (an all-zero valid token divides by zero there too)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v[u].x /= nrm; v[u].y /= nrm; v[u].z /= nrm; v[u].w /= nrm; }
+            }
+        }
+        const float sg = negate ? -1.f : 1.f;
+        uint32_t pk[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const __bf16 b0 = (__bf16)(sg * v[u].x), b1 = (__bf16)(sg * v[u].y), b2 = (__bf16)(sg * v[u].z), b3 = (__bf16)(sg * v[u].w);
+            pk[2 * u] = (uint32_t)__builtin_bit_cast(uint16_t, b0) | ((uint32_t)__builtin_bit_cast(uint16_t, b1) << 16);
+            pk[2 * u + 1] = (uint32_t)__builtin_bit_cast(uint16_t, b2) | ((uint32_t)__builtin_bit_cast(uint16_t, b3) << 16);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(hn + ((size_t)seq * Tp + tok) * FD + 16 * l8);
+        dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        return;
     }
     for (int r = w; r < 32; r += 4) {
         const int tok = tile * 32 + r;

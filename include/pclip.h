@@ -159,6 +159,7 @@ int pclip_filip_loss(const float* sim_A, const float* sim_B, int Br, int Bc, int
  * h [B,T,d] f32, mask [B,T] u8 (used by value, as the reference multiplies by the mask),
  * mean [B,d] f32, inv_count [B] f32 = 1 / max(sum mask, 1) (kept for the backward).
  * Backward: dh[b,t,:] = mask[b,t] * g[b,:] * inv_count[b]   (dh is OVERWRITTEN).
+ * When d is a multiple of 4, h, g and dh must be 16-byte aligned (rejected otherwise).
  * ------------------------------------------------------------------------------------- */
 int pclip_masked_mean_fwd(const float* h, const uint8_t* mask, int B, int T, int d, float* mean, float* inv_count, void* stream);
 int pclip_masked_mean_bwd(const float* g, const uint8_t* mask, const float* inv_count, int B, int T, int d, float* dh, void* stream);

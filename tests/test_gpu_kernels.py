@@ -326,7 +326,7 @@ def test_masked_mean_matches_the_reference_formula(K):
     the same formula, widths with and without a 16-byte row pitch, an empty sequence, int64 masks."""
     from protein_clip_amd import ops
     gen = torch.Generator().manual_seed(12)
-    for B, T, d in [(3, 7, 128), (5, 300, 128), (2, 33, 20), (4, 65, 130), (1, 1, 7)]:
+    for B, T, d in [(3, 7, 128), (5, 300, 128), (2, 33, 20), (4, 65, 130), (1, 1, 7), (2, 70, 132), (3, 40, 256)]:
         h = torch.randn(B, T, d, generator=gen)
         mask = (torch.rand(B, T, generator=gen) > 0.4).to(torch.int64)
         if B > 1:

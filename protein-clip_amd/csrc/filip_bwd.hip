@@ -373,8 +373,12 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
         }
     }
     if (!valid && p.nwt > 1) return;   // the window sum writes the zero rows of padding tokens itself
-    out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    // streaming stores: the partials (268 MB per launch at the benchmark shape) do not push the window's images out of
+    // the L2 (gather 346 -> 334 us; the pass that sums them then reads them from HBM, 42 -> 50 us)
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
+    __builtin_nontemporal_store(v0, reinterpret_cast<f32x4v*>(out));
+    __builtin_nontemporal_store(v1, reinterpret_cast<f32x4v*>(out) + 1);
 }
 
 // out = sum of the nslot partial gradients (n4 float4 each); rows of padding tokens (never

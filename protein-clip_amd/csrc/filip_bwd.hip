@@ -391,12 +391,12 @@ __global__ __launch_bounds__(256) void filip_window_sum_kernel(const float4* __r
     const int o = (int)(row / TOp), a = (int)(row - (size_t)o * TOp);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((mwO[(size_t)o * (TOp >> 5) + (a >> 5)] >> (a & 31)) & 1u) {
-        const float4* pr = part + row * nslot * (FD / 4) + (k - row * (FD / 4));   // [row][slot][128]
-        s = pr[0];
-        for (int x = 1; x < nslot; ++x) {
-            const float4 v = pr[(size_t)x * (FD / 4)];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
+        // streaming loads: the partials are read once and are larger than the memory-side cache
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const f32x4v* pr = reinterpret_cast<const f32x4v*>(part + row * nslot * (FD / 4) + (k - row * (FD / 4)));   // [row][slot][128]
+        f32x4v a = __builtin_nontemporal_load(pr);
+        for (int x = 1; x < nslot; ++x) a += __builtin_nontemporal_load(pr + (size_t)x * (FD / 4));
+        s = make_float4(a.x, a.y, a.z, a.w);
     }
     out[k] = s;
 }

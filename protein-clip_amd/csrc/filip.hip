@@ -117,10 +117,8 @@ __global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __rest
     // without being read.
     const bool negate = tsign && tsign[0] < 0.f;
     const int lane = threadIdx.x & 63;
-    // last rows first: the gradient rows written last by the kernel before are the ones still in the memory-side cache
-    const size_t rrow = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (rrow >= (size_t)B * T) return;
-    const size_t row = (size_t)B * T - 1 - rrow;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (size_t)B * T) return;
     const int seq = (int)(row / T), tok = (int)(row - (size_t)seq * T);
     const float* hr = h + row * d;
     const float* gr = dn + ((size_t)seq * Tp + tok) * row_stride;

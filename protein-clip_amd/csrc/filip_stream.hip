@@ -35,9 +35,21 @@ unsigned long long* g_stream_dbg = nullptr;
 #else
 #define STAMP(k) do {} while (0)
 #endif
+// Diagnostic build (-DSTREAM_TIMELINE): wall-clock stamps (100 MHz counter) of every workgroup's phases and the CU it
+// ran on, to g_stream_tl[block * 32 + k]: 0 entry, 1 pairing done, 2 set-up done, 3 first epoch landed, 4 + w end of
+// wave w's main loop, 20 end of the workgroup, 21 hardware id, 22 XCC id.
+#ifdef STREAM_TIMELINE
+extern "C" { unsigned long long* g_stream_tl = nullptr; }
+#define TL(k) do { if (p.tl && lane == 0 && w == 0) p.tl[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TL(k) do {} while (0)
+#endif
 #ifndef STREAM_WGS
-#define STREAM_WGS 512       // workgroups aimed at per launch (two per CU): a workgroup's set-up costs about 6 us and
-                             // nothing overlaps it (one workgroup fills a CU's LDS); 1024 is 2 % slower, 2048 4 %
+#define STREAM_WGS 768       // workgroups aimed at per launch (three per CU; one fills a CU's LDS).  A workgroup's set-up costs
+                             // about 9 us and nothing overlaps it, but the pairs differ in cost (3 or 4 tile rounds at ragged
+                             // lengths) and three or four workgroups per CU even that out: benchmark shape 0.700 / 0.690 /
+                             // 0.690 ms with 512 / 768 / 1024, every token valid 0.957 / 0.967 / 0.97; counts that are not a
+                             // multiple of the 256 CUs lose 4-8 %
 #endif
 #ifndef ABL_MFMA_STEPS
 #define ABL_MFMA_STEPS 8   // timing experiments only: fewer k-steps (wrong results)
@@ -58,9 +70,12 @@ struct FilipStreamArgs {
     const float* t;
     float* simA; float* simB;
     uint16_t* argA; uint16_t* argB;
-    int jchunk, ngroups;
+    int jchunk, ngroups, nchunk, cpw;
 #ifdef STREAM_STAMPS
     unsigned long long* dbg;
+#endif
+#ifdef STREAM_TIMELINE
+    unsigned long long* tl;
 #endif
 };
 
@@ -184,11 +199,33 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int grp = blockIdx.x % p.ngroups;
-    const int chunk = blockIdx.x / p.ngroups;
+    // Which (pair of A sequences, chunk of B sequences) this block takes.  The hardware deals the blocks of a launch
+    // round-robin and in order over 8 XCDs x 4 shader engines (block b goes to engine b % 32) and only fills a free CU
+    // of the engine whose turn it is, so an engine's share of the work is the blocks with its residue, and they start
+    // in index order.  With the pairing below the workgroups differ in cost (tile rounds of the pair); the pairs are
+    // therefore ranked by cost and dealt over the 32 engines in snake order (every engine gets the same mix), all
+    // chunks of an engine's heaviest pair first (longest first: the short ones fill the end).
+    int grp = blockIdx.x % p.ngroups;
+    int chunk = blockIdx.x / p.ngroups;
+    int srank = -1;
+#ifndef ABL_NOPAIR
+    if (p.Br <= NW * 64) {
+        // an engine's list: chunks in blocks of `cpw` (what its 8 CUs run at the same time stays within few chunks of B,
+        // which its XCD's L2 then holds), inside a block the pairs heaviest first
+        const int r = blockIdx.x & 31, k = blockIdx.x >> 5;
+        const int rows = (p.ngroups + 31) >> 5, cpw = p.cpw;
+        const int per_block = rows * cpw;
+        const int cb = k / per_block, k2 = k - cb * per_block;
+        const int j = k2 / cpw;
+        chunk = cb * cpw + (k2 - j * cpw);
+        srank = 32 * j + ((j & 1) ? 31 - r : r);
+        if (srank >= p.ngroups || chunk >= p.nchunk) return;
+    }
+#endif
     const int j_begin = chunk * p.jchunk, j_end = min(p.Bc, j_begin + p.jchunk);
     const int nj = j_end - j_begin;
     const int ntA = p.TAp >> 5, ntB = p.TBp >> 5;
+    TL(0);
 
     // ---- which two A sequences: pairs whose valid-tile counts sum to a multiple of four --------
     // Sixteen waves sit on four SIMDs, so a workgroup takes ceil(tiles / 4) tile rounds per B
@@ -201,11 +238,15 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     if (p.Br <= NW * 64) {
         int* wtot = reinterpret_cast<int*>(smem + C::S_RING);                   // [NW][4] class counts per wave
         uint16_t* pairmem = reinterpret_cast<uint16_t*>(smem + C::S_RING + 1024);  // [ngroups][2]
+        int* ctot = reinterpret_cast<int*>(smem + C::S_RING + 256);                // [NW][8] cost counts per wave
+        uint8_t* ntmem = smem + C::S_RING + 3072;                                   // [Br] valid tiles of a sequence
+        uint16_t* sortedmem = reinterpret_cast<uint16_t*>(smem + C::S_RING + 4096);  // [ngroups] pairs, heaviest first
         int cls = -1;
         if (tid < p.Br) {
             int nt = 0;
             for (int k = 0; k < ntA; ++k) nt += p.mwA[(size_t)tid * ntA + k] != 0u;
             cls = nt & 3;
+            ntmem[tid] = (uint8_t)nt;
         }
         int rank = 0;
 #pragma unroll
@@ -232,6 +273,33 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
             pairmem[2 * pid + pos] = (uint16_t)tid;
         }
         __syncthreads();
+        {   // rank the pairs by cost = tile rounds of their workgroups (ceil(tiles / 4)), heaviest first, ties in index order
+            int cost = -1;
+            if (tid < p.ngroups) {
+                const int m0 = pairmem[2 * tid], m1 = pairmem[2 * tid + 1];
+                cost = ((m0 != 0xFFFF ? (int)ntmem[m0] : 0) + (m1 != 0xFFFF ? (int)ntmem[m1] : 0) + 3) >> 2;
+            }
+            int crank = 0;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                const unsigned long long m = __ballot(cost == 4 - v);
+                if (cost == 4 - v) crank = __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == 0) ctot[w * 8 + v] = __popcll(m);
+            }
+            __syncthreads();
+            if (cost >= 0) {
+                const int v = 4 - cost;
+                int base = 0;
+                const int nwv = (p.ngroups + 63) >> 6;   // waves that hold pairs
+                for (int k = 0; k < nwv; ++k)
+#pragma unroll
+                    for (int u = 0; u < 5; ++u)
+                        if (u < v || (u == v && k < w)) base += ctot[k * 8 + u];
+                sortedmem[base + crank] = (uint16_t)tid;
+            }
+            __syncthreads();
+            grp = sortedmem[srank];
+        }
         const int a0 = pairmem[2 * grp], a1 = pairmem[2 * grp + 1];
         iseq[0] = a0 == 0xFFFF ? -1 : a0;
         iseq[1] = a1 == 0xFFFF ? -1 : a1;
@@ -241,6 +309,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
 #endif
     iseq[0] = __builtin_amdgcn_readfirstlane(iseq[0]);
     iseq[1] = __builtin_amdgcn_readfirstlane(iseq[1]);
+    TL(1);
 #define ISEQ(isel) ((isel) ? iseq[1] : iseq[0])
 
     // ---- set-up: A mask words, column-key array, the B tile stream ---------------------------
@@ -325,6 +394,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
 #pragma unroll
     for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(afr[s]));
 
+    TL(2);
     const int T = __builtin_amdgcn_readfirstlane(cnt_l[0]);
     const int nE = T / SE;
 
@@ -376,6 +446,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    TL(3);
 
     // Emits the two scores of every sequence whose last tile lies in epoch E (all of its parts
     // are complete one barrier after that epoch's own).  One wave does it — the last one when it
@@ -589,11 +660,21 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     if (lane == 0 && p.dbg)
         for (int k = 0; k < 8; ++k) p.dbg[((size_t)blockIdx.x * NW + w) * 8 + k] = seg_[k];
 #endif
+#ifdef STREAM_TIMELINE
+    if (p.tl && lane == 0) p.tl[(size_t)blockIdx.x * 32 + 4 + w] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (nE > 0) {
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         emit_epoch(nE - 1);
     }
+#ifdef STREAM_TIMELINE
+    if (p.tl && lane == 0 && w == 0) {
+        p.tl[(size_t)blockIdx.x * 32 + 20] = __builtin_amdgcn_s_memrealtime();
+        p.tl[(size_t)blockIdx.x * 32 + 21] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+        p.tl[(size_t)blockIdx.x * 32 + 22] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
+#endif
 }
 
 int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
@@ -608,6 +689,9 @@ int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br,
 #ifdef STREAM_STAMPS
     a.dbg = g_stream_dbg;
 #endif
+#ifdef STREAM_TIMELINE
+    a.tl = g_stream_tl;
+#endif
     if (wgs_target < 1 || wgs_target > 65536) wgs_target = STREAM_WGS;
     int nchunk = (wgs_target + a.ngroups - 1) / a.ngroups;   // about two workgroups per CU over the launch
     int jchunk = (Bc + nchunk - 1) / nchunk;
@@ -615,8 +699,20 @@ int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br,
     if (jchunk > SMAXJ) jchunk = SMAXJ;
     nchunk = (Bc + jchunk - 1) / jchunk;
     a.jchunk = jchunk;
+    a.nchunk = nchunk;
     static PclipLdsLimit lds_limit;
     if (int rc = pclip_ensure_lds(lds_limit, (const void*)filip_sim_stream_kernel, C::S_TOTAL, "filip_sim_stream_kernel")) return rc;
-    hipLaunchKernelGGL(filip_sim_stream_kernel, dim3(a.ngroups * nchunk), dim3(C::NW * 64), C::S_TOTAL, (hipStream_t)stream, a);
+    // blocks: one per (pair, chunk); with the cost-ranked dealing the pairs are padded to whole rows of 32 (see the kernel)
+    unsigned nblocks = (unsigned)(a.ngroups * nchunk);
+    a.cpw = 1;
+#ifndef ABL_NOPAIR
+    if (Br <= C::NW * 64) {
+        const int rows = (a.ngroups + 31) / 32;
+        a.cpw = rows >= 8 ? 1 : 8 / rows;                                  // chunks that an engine's 8 CUs work on together
+        const int nblk = (nchunk + a.cpw - 1) / a.cpw;                     // chunk blocks (the last one may be short)
+        nblocks = (unsigned)(32 * rows * a.cpw * nblk);
+    }
+#endif
+    hipLaunchKernelGGL(filip_sim_stream_kernel, dim3(nblocks), dim3(C::NW * 64), C::S_TOTAL, (hipStream_t)stream, a);
     return pclip_check_launch("filip_sim_stream_kernel");
 }

@@ -681,6 +681,28 @@ def test_filip_sequences_beyond_one_lds_image(K, TA, TB, normalise):
     close(dt, dt_ref.reshape(1), 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("Br", [70, 600, 1030])
+def test_filip_scores_with_many_a_sequences(K, Br):
+    """Batches of many short A sequences: more pairs than one row of the score kernel's cost-ranked dealing (32),
+    more than one wave of pairs (128), and beyond the size up to which the pairing runs at all (1024): ragged
+    lengths with empty sequences in between, scores against the oracle."""
+    gen = torch.Generator().manual_seed(Br)
+    Bc, TA, TB, d = 24, 70, 45, 32
+    hA, hB = torch.randn(Br, TA, d, generator=gen), torch.randn(Bc, TB, d, generator=gen)
+    lA = torch.randint(0, TA + 1, (Br,), generator=gen)
+    lB = torch.randint(1, TB + 1, (Bc,), generator=gen)
+    lA[::7] = TA
+    mA = (torch.arange(TA)[None] < lA[:, None]).to(torch.uint8)
+    mB = (torch.arange(TB)[None] < lB[:, None]).to(torch.uint8)
+    t = torch.tensor(0.8)
+    hA, hB = O.bf16_round(O.filip_normalise(hA)), O.bf16_round(O.filip_normalise(hB))   # the same bf16 operands on both sides
+    sA, sB = O.filip_similarity(hA, hB, mA, mB, t, block=64)
+    hnA, mwA, hnB, mwB, simA, simB, argA, argB = _filip_fwd(K, hA, hB, mA, mB, t, normalise=False, unit=True)
+    live = (lA > 0)[:, None].expand(Br, Bc)
+    assert torch.allclose(simA.cpu()[live], sA[live], rtol=2e-6, atol=3e-6)
+    assert torch.allclose(simB.cpu()[live], sB[live], rtol=2e-6, atol=3e-6)
+
+
 def test_filip_random_small_shapes_against_oracle(K):
     """Seeded sweep over awkward shapes: batch sizes 1..19 (odd ones leave a workgroup with one A
     sequence), token counts around the 32-token tile edges, narrow embeddings, random (not only

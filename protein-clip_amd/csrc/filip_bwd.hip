@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
     const int slot = blockIdx.x % nslot, blk = blockIdx.x / nslot;
     const int x = p.win0 + slot;
     const int o = blk / chunks;
-    const int a = (blk - o * chunks) * 16 + grp;
+    const int a = ((blk - o * chunks + o) % chunks) * 16 + grp;   // rotated by the sequence: a shader engine (block % 4 here) sees every chunk position
     const int q_lo = x * p.qpw, q_hi = min(p.Np, q_lo + p.qpw);
     const bool valid = (p.mwO[(size_t)o * (p.TOp >> 5) + (a >> 5)] >> (a & 31)) & 1u;
     // the partials of one gradient row lie next to each other ([row][slot][128]): the pass that

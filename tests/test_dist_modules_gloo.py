@@ -119,10 +119,16 @@ def _worker(rank, port, out_dir):
 @pytest.fixture(scope="module")
 def two_rank_results(tmp_path_factory):
     out_dir = str(tmp_path_factory.mktemp("gloo_modules"))
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    mp.start_processes(_worker, args=(port, out_dir), nprocs=WORLD, join=True, start_method="spawn")
+    for attempt in range(3):   # the port is free when it is picked; another process may take it before the ranks meet
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        try:
+            mp.start_processes(_worker, args=(port, out_dir), nprocs=WORLD, join=True, start_method="spawn")
+            break
+        except Exception:
+            if attempt == 2:
+                raise
     res = [torch.load(os.path.join(out_dir, f"rank{r}.pt"), weights_only=False) for r in range(WORLD)]
     res.append(out_dir)
     return res

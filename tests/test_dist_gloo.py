@@ -62,16 +62,18 @@ def _worker(rank, port, out_dir):
 
 @pytest.fixture(scope="module")
 def two_rank_results(tmp_path_factory):
-    out_dir = str(tmp_path_factory.mktemp("gloo"))
     import socket
+    import sys
     for attempt in range(3):   # the port is free when it is picked; another process may take it before the ranks meet
+        out_dir = str(tmp_path_factory.mktemp("gloo"))   # a fresh directory: a failed attempt may have left files
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         try:
             mp.start_processes(_worker, args=(port, out_dir), nprocs=WORLD, join=True, start_method="spawn")
             break
-        except Exception:
+        except Exception as e:
+            print(f"two-rank attempt {attempt} failed: {e!r}", file=sys.stderr)
             if attempt == 2:
                 raise
     return [torch.load(os.path.join(out_dir, f"rank{r}.pt"), weights_only=True) for r in range(WORLD)]

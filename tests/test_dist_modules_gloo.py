@@ -118,15 +118,16 @@ def _worker(rank, port, out_dir):
 
 @pytest.fixture(scope="module")
 def two_rank_results(tmp_path_factory):
-    out_dir = str(tmp_path_factory.mktemp("gloo_modules"))
     for attempt in range(3):   # the port is free when it is picked; another process may take it before the ranks meet
+        out_dir = str(tmp_path_factory.mktemp("gloo_modules"))   # a fresh directory: a failed attempt may have left files
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         try:
             mp.start_processes(_worker, args=(port, out_dir), nprocs=WORLD, join=True, start_method="spawn")
             break
-        except Exception:
+        except Exception as e:
+            print(f"two-rank attempt {attempt} failed: {e!r}", file=sys.stderr)
             if attempt == 2:
                 raise
     res = [torch.load(os.path.join(out_dir, f"rank{r}.pt"), weights_only=False) for r in range(WORLD)]

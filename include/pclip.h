@@ -216,7 +216,7 @@ int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, i
  * f32 rounding of an accumulation that starts at 4.0: maxima within 2e-6, near-ties closer than
  * that may pick either token); unit_norm = 0 makes no assumption (exact f32 maxima, slower).
  * A value of 2 or more is unit_norm = 1 with that number of workgroups aimed at per launch
- * instead of the default of 512 (tuning and tests; results do not depend on it).
+ * instead of the default of 768 (tuning and tests; results do not depend on it).
  *   sim_A, sim_B [Br,Bc] f32
  *   argA [Br,Bc,TAp] u16: for each valid a the b attaining the max
  *   argB [Br,Bc,TBp] u16: for each valid b the a attaining the max

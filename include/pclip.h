@@ -250,6 +250,16 @@ int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int
                         const uint16_t* argA, const uint16_t* argB,
                         const float* gA, const float* gB,
                         float* dnA, float* dnB, float* dt, void* ws, size_t ws_bytes, void* stream);
+/* The second of two one-sided calls on the same workspace (same inputs, the other side): the
+ * marks of the token pairs that chose each other, which the first call left in `ws`, are used
+ * again instead of being recomputed.  No counterpart in the reference; it serves the split
+ * described above (modules/models.py:221-245 has one backward for both sides). */
+int pclip_filip_sim_bwd_resume(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
+                               const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,
+                               const float* t, const float* sim_A, const float* sim_B,
+                               const uint16_t* argA, const uint16_t* argB,
+                               const float* gA, const float* gB,
+                               float* dnA, float* dnB, float* dt, void* ws, size_t ws_bytes, void* stream);
 
 /* Steps 3 and 4 in one call, for callers that want d loss / d (raw token embeddings) and have
  * no use for dn (no gradient exchange between the two): same inputs as pclip_filip_sim_bwd plus

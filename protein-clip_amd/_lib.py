@@ -45,6 +45,7 @@ _SIGNATURES = {
     "pclip_filip_sim_fwd": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P]),
     "pclip_filip_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pclip_filip_sim_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "pclip_filip_sim_bwd_resume": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "pclip_filip_bwd_fused_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pclip_filip_bwd_fused": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "pclip_filip_prep_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),

@@ -488,7 +488,7 @@ static int bwd_gather_side(FilipBwdArgs a, float* part, float* dn, const BwdTail
 static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
                          int TB, const float* t, const float* sim_A, const float* sim_B, const uint16_t* argA, const uint16_t* argB,
                          const float* gA, const float* gB, float* dnA, float* dnB, const BwdTail& tailA, const BwdTail& tailB, float* dt,
-                         void* ws, size_t ws_bytes, void* stream) {
+                         void* ws, size_t ws_bytes, void* stream, bool marks_in_ws = false) {
     PCLIP_REQUIRE(hnA && maskwA && hnB && maskwB && t && sim_A && sim_B && argA && argB && gA && gB && dt && ws, "filip backward: null pointer");
     PCLIP_REQUIRE(Br >= 1 && Bc >= 1 && Br <= 65535 && Bc <= 65535, "filip backward: Br=%d Bc=%d (need 1..65535)", Br, Bc);
     PCLIP_REQUIRE(TA >= 1 && TA <= PCLIP_FILIP_MAX_T_LONG && TB >= 1 && TB <= PCLIP_FILIP_MAX_T_LONG, "filip backward: TA=%d TB=%d (need 1..%d)",
@@ -520,7 +520,7 @@ static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
     }
     uint32_t* mutA = (uint32_t*)(w + L.mutA);
     uint32_t* mutB = (uint32_t*)(w + L.mutB);
-    {
+    if (!marks_in_ws) {
         const size_t lds = (size_t)4 * (TAp + TBp) * sizeof(uint16_t);
         static PclipLdsLimit lds_limit;
         if (int rc = pclip_ensure_lds(lds_limit, (const void*)filip_mutual_kernel, lds, "filip_mutual_kernel")) return rc;
@@ -564,6 +564,16 @@ extern "C" int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, 
     const BwdTail none = {nullptr, nullptr, 0, 0, 0, nullptr};
     return filip_bwd_impl(hnA, maskwA, Br, TA, hnB, maskwB, Bc, TB, t, sim_A, sim_B, argA, argB, gA, gB, dnA, dnB, none, none, dt, ws, ws_bytes,
                           stream);
+}
+
+extern "C" int pclip_filip_sim_bwd_resume(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB,
+                                          const uint32_t* maskwB, int Bc, int TB, const float* t, const float* sim_A, const float* sim_B,
+                                          const uint16_t* argA, const uint16_t* argB, const float* gA, const float* gB, float* dnA,
+                                          float* dnB, float* dt, void* ws, size_t ws_bytes, void* stream) {
+    PCLIP_REQUIRE(dnA || dnB, "filip_sim_bwd_resume: null pointer (dnA and dnB)");
+    const BwdTail none = {nullptr, nullptr, 0, 0, 0, nullptr};
+    return filip_bwd_impl(hnA, maskwA, Br, TA, hnB, maskwB, Bc, TB, t, sim_A, sim_B, argA, argB, gA, gB, dnA, dnB, none, none, dt, ws, ws_bytes,
+                          stream, true);
 }
 
 extern "C" int pclip_filip_bwd_fused(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,

@@ -339,9 +339,12 @@ def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True
     return simA, simB, argA, argB
 
 
-def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt: Optional[torch.Tensor] = None, sides: str = "AB"):
+def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt: Optional[torch.Tensor] = None, sides: str = "AB",
+                  resume: bool = False):
     """Returns (dnA, dnB, dt).  ``sides``: "AB" (both), "A" (dnA and dt; dnB is None) or "B" (dnB only;
-    dnA and dt are None) — the multi-GPU step runs "B" first and reduce-scatters dnB while "A" runs."""
+    dnA and dt are None) — the multi-GPU step runs "B" first and reduce-scatters dnB while "A" runs.
+    ``resume``: this is the second of two one-sided calls with the same inputs, directly after the first on
+    the same stream (the workspace still holds the first call's marks of mutual choices)."""
     dev = hnA.device
     Br, Bc = hnA.shape[0], hnB.shape[0]
     tt = _scalar(t, dev, "t")
@@ -353,9 +356,10 @@ def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB,
         dt = torch.zeros(1, dtype=F32, device=dev)
     lib = _lib.load()
     ws = _workspace(dev, lib.pclip_filip_bwd_workspace_bytes(Br, TA, Bc, TB))
-    check(lib.pclip_filip_sim_bwd(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), ptr(simA), ptr(simB),
-                                  ptr(argA), ptr(argB), ptr(gA), ptr(gB), ptr(dnA), ptr(dnB), ptr(dt), ptr(ws), ws.numel(),
-                                  stream_of(hnA)), "pclip_filip_sim_bwd")
+    entry = lib.pclip_filip_sim_bwd_resume if resume else lib.pclip_filip_sim_bwd
+    check(entry(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), ptr(simA), ptr(simB),
+                ptr(argA), ptr(argB), ptr(gA), ptr(gB), ptr(dnA), ptr(dnB), ptr(dt), ptr(ws), ws.numel(),
+                stream_of(hnA)), "pclip_filip_sim_bwd")
     return dnA, dnB, (dt if "A" in sides else None)
 
 

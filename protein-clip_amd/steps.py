@@ -119,7 +119,7 @@ class FilipShardedStep:
             _, dnB_all, _ = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB, sides="B")
             dnB = torch.empty((Bl,) + tuple(dnB_all.shape[1:]), dtype=dnB_all.dtype, device=dnB_all.device)
             work = dist.reduce_scatter_tensor(dnB, dnB_all, group=self.group, async_op=True)
-            dnA, _, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB, sides="A")
+            dnA, _, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB, sides="A", resume=True)
             dhA = K.filip_prep_bwd(hA, dnA, True, tsign=t)
             work.wait()
             dhB = K.filip_prep_bwd(hB, dnB, True)

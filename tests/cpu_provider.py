@@ -165,7 +165,7 @@ def filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, want_arg=True, unit_norm=False,
     return simA, simB, aA.to(torch.int16), aB.to(torch.int16)
 
 
-def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt=None, sides="AB"):
+def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt=None, sides="AB", resume=False):
     a = hnA.detach().clone().requires_grad_(True)
     b = hnB.detach().clone().requires_grad_(True)
     with torch.enable_grad():

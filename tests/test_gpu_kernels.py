@@ -681,6 +681,28 @@ def test_filip_sequences_beyond_one_lds_image(K, TA, TB, normalise):
     close(dt, dt_ref.reshape(1), 1e-4, 1e-5)
 
 
+def test_filip_backward_in_two_one_sided_calls(K):
+    """The multi-GPU step's split (steps.py): B side first, then the A side resumed on the same workspace
+    (pclip_filip_sim_bwd_resume keeps the first call's marks of mutual choices): both equal the one call for both
+    sides, single window and windowed."""
+    for (Br, Bc, T) in [(5, 7, 40), (40, 72, 256)]:
+        gen = torch.Generator().manual_seed(Br)
+        hA, hB = torch.randn(Br, T, 128, generator=gen), torch.randn(Bc, T, 128, generator=gen)
+        lA, lB = torch.randint(1, T + 1, (Br,), generator=gen), torch.randint(1, T + 1, (Bc,), generator=gen)
+        mA = (torch.arange(T)[None] < lA[:, None]).to(torch.uint8)
+        mB = (torch.arange(T)[None] < lB[:, None]).to(torch.uint8)
+        t = torch.tensor(0.9)
+        hnA, mwA, hnB, mwB, simA, simB, argA, argB = _filip_fwd(K, hA, hB, mA, mB, t, normalise=True)
+        gA, gB = dev(torch.randn(Br, Bc, generator=gen)), dev(torch.randn(Br, Bc, generator=gen))
+        tt = dev(t.reshape(1))
+        dnA, dnB, dt = K.filip_sim_bwd(hnA, mwA, T, hnB, mwB, T, tt, simA, simB, argA, argB, gA, gB)
+        _, dnB2, _ = K.filip_sim_bwd(hnA, mwA, T, hnB, mwB, T, tt, simA, simB, argA, argB, gA, gB, sides="B")
+        dnA2, _, dt2 = K.filip_sim_bwd(hnA, mwA, T, hnB, mwB, T, tt, simA, simB, argA, argB, gA, gB, sides="A", resume=True)
+        close(dnA2, dnA.cpu(), 1e-5, 2e-6)   # the order of a bucket's entries, hence of the sums, is not fixed
+        close(dnB2, dnB.cpu(), 1e-5, 2e-6)
+        close(dt2, dt.cpu(), 1e-5, 1e-6)
+
+
 @pytest.mark.parametrize("Br", [70, 600, 1030])
 def test_filip_scores_with_many_a_sequences(K, Br):
     """Batches of many short A sequences: more pairs than one row of the score kernel's cost-ranked dealing (32),

@@ -798,7 +798,7 @@ def test_filip_fused_backward_equals_the_two_calls(K, Br, Bc, TA, TB):
 
 
 def test_filip_scores_do_not_depend_on_the_workgroup_count():
-    """The streaming kernel cuts the B side into chunks by a workgroup target (512 by default):
+    """The streaming kernel cuts the B side into chunks by a workgroup target (768 by default):
     scores and arg-max tables are bit-identical for every cut."""
     import importlib.util
     import os

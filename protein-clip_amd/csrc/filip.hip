@@ -20,7 +20,11 @@ __global__ __launch_bounds__(256) void filip_prep_kernel(const float* __restrict
                                                          uint16_t* __restrict__ hn, uint32_t* __restrict__ maskw) {
     const bool negate = tsign && tsign[0] < 0.f;
     const int ntile = Tp >> 5;
-    const int seq = blockIdx.x / ntile, tile = blockIdx.x - seq * ntile;
+    // The hardware deals block b to XCD b % 8 (and to shader engine (b / 8) % 4 inside it): with tile = b % ntile an XCD
+    // would always get the same tile position, and the late tiles of ragged sequences are padding.  Rotated by the
+    // sequence, every XCD sees every position.
+    const int seq = blockIdx.x / ntile;
+    const int tile = (blockIdx.x - seq * ntile + seq) % ntile;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (w == 0) {
         const int tok = tile * 32 + (lane & 31);
@@ -117,7 +121,14 @@ __global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __rest
     // without being read.
     const bool negate = tsign && tsign[0] < 0.f;
     const int lane = threadIdx.x & 63;
-    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // groups of eight blocks (32 rows) go to one shader engine: the group's place inside its sequence is rotated by the
+    // sequence, so that an engine does not always get the same token range (the late ones are padding at ragged lengths)
+    size_t blk = blockIdx.x;
+    if ((T & 31) == 0) {
+        const size_t gps = (size_t)(T >> 5), grp = blk >> 3, s = grp / gps;
+        blk = ((s * gps + (grp - s * gps + s) % gps) << 3) | (blk & 7);
+    }
+    const size_t row = blk * 4 + (threadIdx.x >> 6);
     if (row >= (size_t)B * T) return;
     const int seq = (int)(row / T), tok = (int)(row - (size_t)seq * T);
     const float* hr = h + row * d;

@@ -566,8 +566,11 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 // ---- rows of the finished B sequence: transpose the keys, lane (row, half) scans 16 ----
                 int* tr = reinterpret_cast<int*>(smem + C::S_TR) + w * 32 * 36;
                 {
-                    int* trw = tr + 4 * h * 36 + c;
-                    asm volatile("" : "+v"(trw));   // the address arithmetic belongs to this branch, not to every product
+                    // an LDS-space pointer (32 bits): passed through an empty asm so that its arithmetic belongs to this
+                    // branch and not to every product — as a generic pointer the sixteen writes became flat stores
+                    typedef __attribute__((address_space(3))) int lds_int;
+                    lds_int* trw = (lds_int*)(tr + 4 * h * 36 + c);
+                    asm volatile("" : "+v"(trw));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) trw[((r & 3) + 8 * (r >> 2)) * 36] = KM[r];
                 }

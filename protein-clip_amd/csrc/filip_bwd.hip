@@ -258,7 +258,8 @@ __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs 
         if (tid == 0) seg[p.TOp] = total;
     }
     __syncthreads();
-    uint32_t* dst = stage ? sorted : list;   // LDS stage or straight to global memory
+    // (the target is the LDS stage or global memory: written as two stores, since one store through a pointer that may
+    // be either is a flat instruction, slower than an LDS write)
     for (int v = tid, u = 0; v < nvec; v += INV_THREADS, ++u) {
         const int ql = v / vpr, pt0 = (v - ql * vpr) * 8, q = q_lo + ql;
         uint32_t m8;
@@ -281,7 +282,9 @@ __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs 
         for (int k = 0; k < 8; ++k)
             if ((m8 >> k) & 1u) {
                 const int pos = atomicAdd(&hist[(dw[k >> 1] >> (16 * (k & 1))) & 0xffffu], 1);
-                dst[pos] = ((uint32_t)q << 16) | (uint32_t)(pt0 + k);
+                const uint32_t ent = ((uint32_t)q << 16) | (uint32_t)(pt0 + k);
+                if (stage) sorted[pos] = ent;
+                else list[pos] = ent;
             }
     }
     if (stage) {

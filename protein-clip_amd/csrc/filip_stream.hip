@@ -30,7 +30,7 @@
 // Diagnostic build (-DSTREAM_STAMPS): every wave adds up the shader-clock cycles it spends in
 // eight segments of the main loop and stores them to g_stream_dbg[(block*16 + wave)*8 + k].
 #ifdef STREAM_STAMPS
-unsigned long long* g_stream_dbg = nullptr;
+extern "C" { unsigned long long* g_stream_dbg = nullptr; }
 #define STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); seg_[k] += (unsigned)(now_ - last_); last_ = now_; } while (0)
 #else
 #define STAMP(k) do {} while (0)

@@ -236,8 +236,8 @@ int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int
  * d loss / d sim_B.  Outputs (f32, OVERWRITTEN): dnA [Br,TA,128p] and dnB [Bc,TB,128p] hold
  * d loss / d (normalised operand) in the padded [.,Tp,128] layout of prep; dt is
  * ACCUMULATED: dt += -(1/t) * sum(gA*sim_A + gB*sim_B).  `ws` holds the bucketed token lists
- * (sized by pclip_filip_bwd_workspace_bytes; about 4*Br*Bc*(TAp+TBp) bytes, plus eight
- * partial copies of dnA and dnB when the operand images exceed the L2 window budget of 2 MB).
+ * (sized by pclip_filip_bwd_workspace_bytes; about 4*Br*Bc*(TAp+TBp) bytes, plus four
+ * partial copies of dnA and dnB when the operand images exceed the L2 window budget of 4 MB).
  * The order in
  * which a row's contributions are summed is not fixed, so results may differ in the last
  * bits from run to run.  Either of dnA, dnB may be NULL: that side is skipped (dt is produced

@@ -11,15 +11,21 @@
 //
 // The partner images of a whole batch (tens of MB) do not fit the 4-MiB L2 of an XCD, and
 // row gathers served from beyond L2 run at half the rate.  So the partners are cut into
-// windows of about 2 MB of images; a gather launch covers eight consecutive windows, with
-// workgroup b on window b % 8 — blocks b and b + 8 are dispatched to the same XCD, so each
-// XCD's L2 only ever sees one window's images during a launch — and writes (first launch) or
-// adds to (later launches, for partner sets beyond eight windows) one of eight PARTIAL
-// gradients; a last pass sums the eight partials.
+// windows of about 4 MB of padded images (about 3 MB of valid rows with ragged lengths); a
+// gather launch covers four consecutive windows, with workgroup b on window b % 4 — blocks b
+// and b + 8 are dispatched to the same XCD, so each XCD's L2 only ever sees one window's images
+// during a launch, and XCDs k and k + 4 share a window, each taking every other 16-token chunk
+// of the own sequences — and writes (first launch) or adds to (later launches, for partner
+// sets beyond four windows) one of four PARTIAL gradients; a last pass sums the partials.
+// (Eight windows of 2 MB, one XCD each, hit the L2 a little more often but write and re-read
+// twice the partials: gather 306 -> 277 us, prep backward 42 -> 37 us at the benchmark shape.
+// Two windows of 8 MB miss the L2: 319 us.)
 #include "pclip_common.h"
 
 #define FD 128
-#define BWD_XCDS 8          // windows per gather launch = partial gradients
+#define BWD_WINS 4           // windows per gather launch = partial gradients
+#define BWD_SHARE 2          // XCDs on one window (BWD_WINS * BWD_SHARE = the 8 XCDs)
+#define BWD_WIN_BYTES ((size_t)4 << 20)
 
 struct FilipBwdArgs {
     const uint16_t* hnP;   // partner images [Np][TPp][128] bf16
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void filip_mutual_kernel(const uint16_t* __res
 // memory made the earlier one-workgroup-per-sequence form four times slower); a window too
 // large for the LDS stage scatters straight to global memory instead.
 // Dynamic LDS: TOp counters, then `stage` entries.
-#define INV_THREADS 512
+#define INV_THREADS 1024      // a 4-MB window stages 64 KB: two workgroups per CU, so 1024 threads each for full occupancy
 #define INV_STAGE_MAX 24576   // entries (96 KB)
 #define INV_KEEP 2            // 8-entry vectors a thread keeps in registers between the two passes
 __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs p, int stage) {
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs 
     __syncthreads();
     const bool own_live = p.icO[o] > 0.f;
     const int nvec = (own_live && q_hi > q_lo) ? (q_hi - q_lo) * vpr : 0;
-    // the first INV_KEEP vectors of a thread stay in registers for the second pass (a 2-MB window
+    // the first INV_KEEP vectors of a thread stay in registers for the second pass (a 4-MB window
     // of 256-token partners is exactly two per thread), later ones are read again
     uint4 keep_d[INV_KEEP];
     uint32_t keep_m[INV_KEEP];
@@ -300,15 +306,21 @@ __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs 
 __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
     const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
     const int chunks = p.TOp >> 4;
-    const int nslot = p.nwt < BWD_XCDS ? p.nwt : BWD_XCDS;
-    const int slot = blockIdx.x % nslot, blk = blockIdx.x / nslot;
+    const int nslot = p.nwt < BWD_WINS ? p.nwt : BWD_WINS;
+    const int share = nslot > 1 ? BWD_SHARE : 1;
+    // block % 8 is the XCD: its low part picks the window, its high part which chunks of the own sequence
+    const int xcd = blockIdx.x % (nslot * share), blk = blockIdx.x / (nslot * share);
+    const int slot = xcd % nslot, part = xcd / nslot;
     const int x = p.win0 + slot;
-    const int o = blk / chunks;
-    const int a = ((blk - o * chunks + o) % chunks) * 16 + grp;   // rotated by the sequence: a shader engine (block % 4 here) sees every chunk position
+    const int cps = (chunks + share - 1) / share;   // chunks per sharing XCD
+    const int o = blk / cps;
+    const int cidx = (blk - o * cps) * share + part;
+    if (cidx >= chunks) return;
+    const int a = ((cidx + o) % chunks) * 16 + grp;   // rotated by the sequence: a shader engine sees every chunk position
     const int q_lo = x * p.qpw, q_hi = min(p.Np, q_lo + p.qpw);
     const bool valid = (p.mwO[(size_t)o * (p.TOp >> 5) + (a >> 5)] >> (a & 31)) & 1u;
     // the partials of one gradient row lie next to each other ([row][slot][128]): the pass that
-    // sums them reads 4 KB in one piece instead of eight rows 33 MB apart
+    // sums them reads 4 KB in one piece instead of four rows 33 MB apart
     float4* out = reinterpret_cast<float4*>(p.dn + ((((size_t)o * p.TOp + a) * nslot + slot) * FD) + l16 * 8);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.accumulate && valid) {
@@ -407,17 +419,17 @@ __global__ __launch_bounds__(256) void filip_window_sum_kernel(const float4* __r
 // ---- host side -------------------------------------------------------------------------
 static inline int tp32(int T) { return (T + 31) / 32 * 32; }
 
-// Window plan of one gather side.  One window when the partner images fit the budget (2 MB: half
-// an XCD's L2), else windows of about that size in multiples of eight.
+// Window plan of one gather side.  One window when the partner images fit the budget (4 MB of
+// padded images: an XCD's L2), else windows of about that size in multiples of four.
 struct BwdPlan { int nwt, qpw; };
 static BwdPlan bwd_plan(int Np, int TPp) {
-    const size_t per = (size_t)TPp * FD * 2, budget = (size_t)2 << 20;
+    const size_t per = (size_t)TPp * FD * 2, budget = BWD_WIN_BYTES;
     BwdPlan pl;
-    if ((size_t)Np * per <= budget || Np < BWD_XCDS) { pl.nwt = 1; pl.qpw = Np; return pl; }
+    if ((size_t)Np * per <= budget || Np < BWD_WINS) { pl.nwt = 1; pl.qpw = Np; return pl; }
     int qpw = (int)(budget / per);
     if (qpw < 1) qpw = 1;
     int nwt = (Np + qpw - 1) / qpw;
-    nwt = (nwt + BWD_XCDS - 1) / BWD_XCDS * BWD_XCDS;
+    nwt = (nwt + BWD_WINS - 1) / BWD_WINS * BWD_WINS;
     pl.nwt = nwt; pl.qpw = qpw;
     return pl;
 }
@@ -442,8 +454,8 @@ static BwdWs bwd_ws_layout(int Br, int TA, int Bc, int TB) {
     w.gT = off;    off += pclip_align_up((size_t)2 * Br * Bc * 4, 256);   // transposed copies of gA, gB
     w.mutA = off;  off += pclip_align_up((size_t)Br * Bc * (TAp / 32) * 4, 256);   // mutual-choice bits of the A tokens
     w.mutB = off;  off += pclip_align_up((size_t)Br * Bc * (TBp / 32) * 4, 256);
-    w.partA = off; off += w.planA.nwt > 1 ? pclip_align_up((size_t)BWD_XCDS * Br * TAp * FD * 4, 256) : 0;   // partials of dnA
-    w.partB = off; off += w.planB.nwt > 1 ? pclip_align_up((size_t)BWD_XCDS * Bc * TBp * FD * 4, 256) : 0;
+    w.partA = off; off += w.planA.nwt > 1 ? pclip_align_up((size_t)BWD_WINS * Br * TAp * FD * 4, 256) : 0;   // partials of dnA
+    w.partB = off; off += w.planB.nwt > 1 ? pclip_align_up((size_t)BWD_WINS * Bc * TBp * FD * 4, 256) : 0;
     w.total = off;
     w.dnA = off; off += w.planA.nwt > 1 ? 0 : pclip_align_up((size_t)Br * TAp * FD * 4, 256);
     w.dnB = off; off += w.planB.nwt > 1 ? 0 : pclip_align_up((size_t)Bc * TBp * FD * 4, 256);
@@ -469,14 +481,15 @@ struct BwdTail {
     const float* tsign;
 };
 
-// gather launches of one side (eight windows each), then the sum of the partials or the fused tail
+// gather launches of one side (four windows each), then the sum of the partials or the fused tail
 static int bwd_gather_side(FilipBwdArgs a, float* part, float* dn, const BwdTail& tail, hipStream_t st) {
-    const int nslot = a.nwt < BWD_XCDS ? a.nwt : BWD_XCDS;
+    const int nslot = a.nwt < BWD_WINS ? a.nwt : BWD_WINS;
+    const int share = nslot > 1 ? BWD_SHARE : 1;
     a.dn = a.nwt > 1 ? part : dn;
-    for (int w0 = 0; w0 < a.nwt; w0 += BWD_XCDS) {
+    for (int w0 = 0; w0 < a.nwt; w0 += BWD_WINS) {
         a.win0 = w0;
         a.accumulate = w0 > 0;
-        hipLaunchKernelGGL(filip_gather_kernel, dim3(a.No * (a.TOp / 16) * nslot), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(filip_gather_kernel, dim3(a.No * ((a.TOp / 16 + share - 1) / share) * nslot * share), dim3(256), 0, st, a);
     }
     const size_t n = (size_t)a.No * a.TOp * FD;
     if (tail.h)   // padding rows of the partials were never written: the mask words keep them out

@@ -436,12 +436,13 @@ def test_filip_backward_matches_oracle(K, filip_cases):
 
 
 def test_filip_backward_partner_windows(K):
-    """The backward cuts the partner sequences into windows of 2 MB of images (eight per gather
-    launch, later launches accumulating) as soon as one side's images exceed that.  40 sequences of
-    up to 256 tokens are 2.6 MB a side: two windows with partners, six empty ones, a batch size that
-    is no multiple of eight, one empty sequence.  Routing and arithmetic as in every other case."""
+    """The backward cuts the partner sequences into windows of 4 MB of images (four per gather
+    launch, later launches accumulating) as soon as one side's images exceed that.  70 sequences of
+    up to 256 tokens are 4.6 MB a side: two windows with partners, two empty ones, a batch size that
+    is no multiple of four, one empty sequence.  Routing and arithmetic as in every other case
+    (a row sums 70 to a few hundred signed terms in f32: 4e-6 of the result's norm, measured 2.6e-6)."""
     gen = torch.Generator().manual_seed(5)
-    B, TA, TB, d = 40, 250, 256, 128
+    B, TA, TB, d = 70, 250, 256, 128
     hA, hB = torch.randn(B, TA, d, generator=gen), torch.randn(B, TB, d, generator=gen)
     lA, lB = torch.randint(1, TA + 1, (B,), generator=gen), torch.randint(1, TB + 1, (B,), generator=gen)
     lB[3] = 0
@@ -450,11 +451,11 @@ def test_filip_backward_partner_windows(K):
     gA, gB = torch.randn(B, B, generator=gen), torch.randn(B, B, generator=gen)
     gA[:, 3] = 0   # scores against the empty sequence are -inf / 0: keep them out of dt
     gB[:, 3] = 0
-    res = _check_routing_and_backward(K, hA, hB, mA, mB, torch.tensor(1.0), True, gA, gB, "windows")
+    res = _check_routing_and_backward(K, hA, hB, mA, mB, torch.tensor(1.0), True, gA, gB, "windows", rtol=4e-6)
     assert torch.isfinite(res[8]).all() and torch.isfinite(res[9]).all() and res[8].abs().sum() > 0
 
 
-def _check_routing_and_backward(K, hA, hB, mA, mB, t, normalise, gA, gB, tag=""):
+def _check_routing_and_backward(K, hA, hB, mA, mB, t, normalise, gA, gB, tag="", rtol=2e-6):
     """The two halves of backward parity, each tight: (1) every valid token's chosen partner attains
     the maximum of its row / column of the similarity tile to 2e-6 (the forward's tolerance);
     (2) with the routing fixed the gradients equal the routed weighted sums of operand rows to f32
@@ -475,7 +476,7 @@ def _check_routing_and_backward(K, hA, hB, mA, mB, t, normalise, gA, gB, tag="")
     wantA, wantB = routed_grads(nA, nB, mAd, mBd, argA, argB, dev(gA), dev(gB), abs(float(t)))
     for got, want in ((dnA[:, :TA], wantA), (dnB[:, :TB], wantB)):
         err = (got.double() - want).norm(dim=-1)
-        assert (err <= 2e-6 * want.norm(dim=-1) + 1e-10 * want.abs().max()).all(), tag
+        assert (err <= rtol * want.norm(dim=-1) + 1e-10 * want.abs().max()).all(), tag
         assert (got[~(want.abs().sum(-1) > 0)] == 0).all(), tag
     return hnA, mwA, hnB, mwB, simA, simB, argA, argB, dnA, dnB, dt
 
@@ -623,7 +624,7 @@ def test_filip_benchmark_size_backward_rows_against_oracle(K):
 
 def test_filip_rank_shape_decomposes_over_partner_blocks(K):
     """One rank of a 3-GPU job: 64 A sequences against 3 x 256 gathered B sequences, L = 256
-    (the backward then needs three gather launches of eight 2-MB windows each).  The two
+    (the backward then needs three gather launches of four 4-MB windows each).  The two
     directions are independent per sequence pair (models.py:332-351), so the scores of a column
     block equal the scores computed against that block alone, and the A gradient is the sum of
     the per-block A gradients."""

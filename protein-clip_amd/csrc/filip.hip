@@ -177,11 +177,70 @@ __global__ __launch_bounds__(256) void filip_prep_bwd_kernel(const float* __rest
     if (k + 1 < d) out[k + 1] = accumulate ? out[k + 1] + o1 : o1;
 }
 
+// The same for the usual case (d a multiple of 4, 16-byte aligned rows, dh overwritten): half a wave per row with
+// 16-byte loads and stores, all slabs of up to four in flight at once, so a wave has twice the bytes on their way.
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void filip_prep_bwd_rows2_kernel(const float* __restrict__ h, const float* __restrict__ dn, int nslab,
+                                                                   size_t slab_stride, size_t row_stride, const uint32_t* __restrict__ mw, int B, int T,
+                                                                   int d, int Tp, int normalise, const float* __restrict__ tsign,
+                                                                   float* __restrict__ dh) {
+    const bool negate = tsign && tsign[0] < 0.f;
+    const int lane = threadIdx.x & 63, l32 = lane & 31;
+    size_t blk = blockIdx.x;   // eight rows per block, four blocks per 32-token group; groups rotated as above
+    if ((T & 31) == 0) {
+        const size_t gps = (size_t)(T >> 5), grp = blk >> 2, s = grp / gps;
+        blk = ((s * gps + (grp - s * gps + s) % gps) << 2) | (blk & 3);
+    }
+    const size_t row = blk * 8 + (threadIdx.x >> 5);
+    if (row >= (size_t)B * T) return;
+    const int seq = (int)(row / T), tok = (int)(row - (size_t)seq * T);
+    const int k = 4 * l32;
+    const bool in = k < d;
+    const bool live = !mw || ((mw[(size_t)seq * (Tp >> 5) + (tok >> 5)] >> (tok & 31)) & 1u);
+    f32x4n v = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+    if (in) v = *reinterpret_cast<const f32x4n*>(h + row * d + k);
+    if (live && in) {
+        const f32x4n* gr = reinterpret_cast<const f32x4n*>(dn + ((size_t)seq * Tp + tok) * row_stride + k);
+        const size_t ss4 = slab_stride >> 2;
+        int s = 0;
+        for (; s + 4 <= nslab; s += 4) {
+            f32x4n p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = __builtin_nontemporal_load(gr + (size_t)(s + u) * ss4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g += p[u];
+        }
+        for (; s < nslab; ++s) g += __builtin_nontemporal_load(gr + (size_t)s * ss4);
+    }
+    const float sgn = negate ? -1.f : 1.f;
+    f32x4n o = g * sgn;
+    if (normalise) {
+        float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        float dot = v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w;
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) {   // the 32 lanes of the row
+            ss += __shfl_xor(ss, m);
+            dot += __shfl_xor(dot, m);
+        }
+        if (ss > 0.f) {
+            const float inv = 1.f / sqrtf(ss);
+            const float ndg = dot * inv * inv;  // (h.g)/|h|^2
+            o = (g - v * ndg) * (inv * sgn);
+        }
+    }
+    if (in) __builtin_nontemporal_store(o, reinterpret_cast<f32x4n*>(dh + row * d + k));
+}
+
 // internal: prep backward over a sum of slabs (used by the fused backward of filip_bwd.hip)
 int filip_prep_bwd_launch(const float* h, const float* dn, int nslab, size_t slab_stride, size_t row_stride, const uint32_t* mw, int B, int T, int d,
                           int normalise, const float* tsign, int accumulate, float* dh, void* stream) {
     const int Tp = (T + 31) / 32 * 32;
     const size_t rows = (size_t)B * T;
+    if ((d & 3) == 0 && !accumulate && (slab_stride & 3) == 0 && (row_stride & 3) == 0 && (((uintptr_t)h | (uintptr_t)dn | (uintptr_t)dh) & 15) == 0) {
+        hipLaunchKernelGGL(filip_prep_bwd_rows2_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, h, dn, nslab, slab_stride,
+                           row_stride, mw, B, T, d, Tp, normalise, tsign, dh);
+        return pclip_check_launch("filip_prep_bwd_rows2_kernel");
+    }
     hipLaunchKernelGGL(filip_prep_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, dn, nslab, slab_stride, row_stride, mw,
                        B, T, d, Tp, normalise, tsign, accumulate, dh);
     return pclip_check_launch("filip_prep_bwd_kernel");

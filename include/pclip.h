@@ -242,7 +242,8 @@ int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int
  * which a row's contributions are summed is not fixed, so results may differ in the last
  * bits from run to run.  Either of dnA, dnB may be NULL: that side is skipped (dt is produced
  * together with dnA), so a caller can run the B side first and start exchanging dnB between
- * GPUs while the A side is computed. */
+ * GPUs while the A side is computed.  The token images of one side may not exceed 4 GB
+ * (Br*TAp and Bc*TBp at most 16,777,215 rows: 32-bit row offsets). */
 size_t pclip_filip_bwd_workspace_bytes(int Br, int TA, int Bc, int TB);
 int pclip_filip_sim_bwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
                         const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs 
 // keeps columns 8*l16..+7.  Index/weight loads are spread over the 16 lanes (16 partners or 16
 // list entries at a time) and broadcast inside the group; the 16 row gathers of a batch are all
 // in flight together.
-__global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void filip_gather_kernel(FilipBwdArgs p) {
     const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
     const int chunks = p.TOp >> 4;
     const int nslot = p.nwt < BWD_WINS ? p.nwt : BWD_WINS;
@@ -331,14 +331,18 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
     if (valid && q_lo < q_hi) {
         const float inv_t = 1.f / fabsf(p.t[0]);
         const float c1 = p.icO[o] * inv_t;
+        // rows are addressed by a scalar base and a 32-bit byte offset per lane (the images of one side stay below
+        // 4 GB: checked by the host), computed once per lane and batch and broadcast inside the group
+        const unsigned char* const img = reinterpret_cast<const unsigned char*>(p.hnP);
+        const uint32_t row_stride = (uint32_t)p.TPp * (FD * 2), lane_off = (uint32_t)l16 * 16u;
         // own-side max terms: one partner row per partner sequence of the window
         for (int q0 = q_lo; q0 < q_hi; q0 += 16) {
             const int q = q0 + l16;
-            int b = 0;
+            uint32_t b = (uint32_t)(q_hi - 1) * row_stride;   // filler past the window's end: weight 0, a row inside the window
             float w = 0.f;
             if (q < q_hi) {
                 const size_t pair = (size_t)o * p.so + (size_t)q * p.sp;
-                b = p.arg1[pair * p.TOp + a];
+                b = ((uint32_t)q * (uint32_t)p.TPp + (uint32_t)p.arg1[pair * p.TOp + a]) * (FD * 2);
                 const float icq = p.icP[q];
                 w = icq > 0.f ? p.g1[(size_t)o * p.gso + (size_t)q * p.gsp] * c1 : 0.f;
                 // b chose a as well: its share of the partner-side term comes with this fetch
@@ -348,10 +352,9 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
             float ws[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const int bk = __shfl(b, k, 16);
+                const uint32_t bk = (uint32_t)__shfl((int)b, k, 16);
                 ws[k] = __shfl(w, k, 16);
-                const int qk = min(q0 + k, q_hi - 1);
-                rows[k] = *reinterpret_cast<const bf16x8*>(p.hnP + ((size_t)qk * p.TPp + bk) * FD + l16 * 8);
+                rows[k] = *reinterpret_cast<const bf16x8*>(img + (bk + lane_off));
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k)
@@ -364,11 +367,12 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
         const int end = seg[1];
         for (int pos0 = seg[0]; pos0 < end; pos0 += 16) {
             const int pos = pos0 + l16;
-            uint32_t ent = (uint32_t)q_lo << 16;   // filler: weight 0, a row inside the window
+            uint32_t ent = 0u;   // byte offset of the entry's row in the partner images
             float w = 0.f;
             if (pos < end) {
-                ent = list[pos];
-                const int q = ent >> 16;
+                const uint32_t e = list[pos];
+                const int q = e >> 16;
+                ent = ((uint32_t)q * (uint32_t)p.TPp + (e & 0xffffu)) * (FD * 2);
                 w = p.g2[(size_t)o * p.gso + (size_t)q * p.gsp] * p.icP[q] * inv_t;
             }
             bf16x8 rows[16];
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void filip_gather_kernel(FilipBwdArgs p) {
                 const uint32_t ek = __shfl(ent, k, 16);
                 ws[k] = __shfl(w, k, 16);
                 // a batch is 16 entries; the lanes past the bucket's end fetch nothing (2 % of the kernel)
-                if (pos0 + k < end) rows[k] = *reinterpret_cast<const bf16x8*>(p.hnP + ((size_t)(ek >> 16) * p.TPp + (ek & 0xffffu)) * FD + l16 * 8);
+                if (pos0 + k < end) rows[k] = *reinterpret_cast<const bf16x8*>(img + (ek + lane_off));
                 else rows[k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
 #pragma unroll
@@ -509,6 +513,9 @@ static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
     PCLIP_REQUIRE(Br >= 1 && Bc >= 1 && Br <= 65535 && Bc <= 65535, "filip backward: Br=%d Bc=%d (need 1..65535)", Br, Bc);
     PCLIP_REQUIRE(TA >= 1 && TA <= PCLIP_FILIP_MAX_T_LONG && TB >= 1 && TB <= PCLIP_FILIP_MAX_T_LONG, "filip backward: TA=%d TB=%d (need 1..%d)",
                   TA, TB, PCLIP_FILIP_MAX_T_LONG);
+    // the gather addresses partner rows by a 32-bit byte offset into one side's images
+    PCLIP_REQUIRE((size_t)Br * tp32(TA) * FD * 2 <= 0xFFFFFFFFull && (size_t)Bc * tp32(TB) * FD * 2 <= 0xFFFFFFFFull,
+                  "filip backward: the token images of one side exceed 4 GB (Br=%d TA=%d Bc=%d TB=%d)", Br, TA, Bc, TB);
     const BwdWs L = bwd_ws_layout(Br, TA, Bc, TB);
     const size_t need = (tailA.h || tailB.h) ? L.total_fused : L.total;
     PCLIP_REQUIRE(ws_bytes >= need, "filip backward: workspace %zu < %zu bytes", ws_bytes, need);

@@ -1,4 +1,5 @@
 // Microbenchmark: how much plain vector work rides beside a chain of v_mfma_f32_32x32x16_bf16?
+// (Mode 3: the same product as sixteen v_mfma_f32_16x16x32_bf16 in four independent chains.)
 // Each wave runs ITER iterations of { 8 dependent MFMAs ; NV integer vector ops on 16 registers
 // of the PREVIOUS iteration's result }, either one after the other (mode 0) or interleaved by
 // sched_group_barrier, VPG vector ops after every MFMA (mode 1).  Prints shader cycles per
@@ -9,6 +10,7 @@
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NV, int MODE, int VPG>
 __global__ __launch_bounds__(1024) void k(const bf16x8* __restrict__ in, int* __restrict__ out, unsigned long long* __restrict__ cyc, int iters) {
@@ -21,14 +23,31 @@ __global__ __launch_bounds__(1024) void k(const bf16x8* __restrict__ in, int* __
     for (int it = 0; it < iters; ++it) {
         const f32x16 two = {2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2};
         asm volatile("" : "+v"(a[0]));   // the operands count as changed: the chain stays in the loop
-        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], two, 0, 0, 0);
+        f32x16 acc;
+        if (MODE == 3) {
+            // the same 32 x 32 x 128 product as four 16 x 16 tiles of v_mfma_f32_16x16x32_bf16: four independent chains of
+            // four instructions (two A and two B fragments per k-step of 32), 16 result registers as before
+            f32x4 c[4];
 #pragma unroll
-        for (int s = 1; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], acc, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) c[q] = f32x4{2, 2, 2, 2};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2 * s + (q >> 1)], b[2 * s + (q & 1)], c[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * q + e] = c[q][e];
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], two, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], acc, 0, 0, 0);
+        }
         // NV vector ops on the previous result: rounds of (and_or, max) over the 16 registers
 #pragma unroll
         for (int v = 0; v < NV / 2; ++v) {
             const int r = v & 15;
-            km[r] = max(km[r], (__float_as_int(MODE == 2 ? acc[r] : prev[r]) & ~7) | (it & 7) | (v >> 4));
+            km[r] = max(km[r], (__float_as_int(MODE >= 2 ? acc[r] : prev[r]) & ~7) | (it & 7) | (v >> 4));
         }
         if (MODE == 1) {
 #pragma unroll
@@ -37,7 +56,7 @@ __global__ __launch_bounds__(1024) void k(const bf16x8* __restrict__ in, int* __
                 __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
             }
         } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MODE == 3 ? 16 : 8, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
         }
         prev = acc;
@@ -98,5 +117,12 @@ int main() {
     run<64, 2, 0>("8 MFMA, 64 VALU on ITS result", in, out, cyc);
     run<96, 2, 0>("8 MFMA, 96 VALU on ITS result", in, out, cyc);
     run<96, 1, 12>("8 MFMA x 12 VALU interleaved", in, out, cyc);
+    run<0, 3, 0>("16 MFMA 16x16x32 only", in, out, cyc);
+    run<32, 3, 0>("16x16x32, 32 VALU on ITS result", in, out, cyc);
+    run<48, 3, 0>("16x16x32, 48 VALU on ITS result", in, out, cyc);
+    run<64, 3, 0>("16x16x32, 64 VALU on ITS result", in, out, cyc);
+    run<72, 3, 0>("16x16x32, 72 VALU on ITS result", in, out, cyc);
+    run<80, 3, 0>("16x16x32, 80 VALU on ITS result", in, out, cyc);
+    run<96, 3, 0>("16x16x32, 96 VALU on ITS result", in, out, cyc);
     return 0;
 }

@@ -57,3 +57,7 @@ def test_bad_arguments_are_rejected_before_launch(lib):
     assert lib.pclip_clip_step_noalloc(one, one, one, 4096, 128, one, one, one, one, None) == -1                      # beyond the built-in scratch
     assert b"built-in buffer" in lib.pclip_last_error()
     assert lib.pclip_rowce_fwd(one, 8, 4, 0, 8, 0, one, one, None) == -1                                              # target column out of range
+    # FILIP backward: the gather addresses partner rows with 32-bit byte offsets, so one side's images stay below 4 GB
+    args = [one, one, 60000, 512, one, one, 8, 64, one, one, one, one, one, one, one, one, one, one, one, 1 << 20, None]
+    assert lib.pclip_filip_sim_bwd(*args) == -1
+    assert b"exceed 4 GB" in lib.pclip_last_error()

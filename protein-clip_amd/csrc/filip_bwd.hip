@@ -46,8 +46,8 @@ struct FilipBwdArgs {
     int* seg;              // [No][nwt][TOp+1] bucket offsets inside the window's list
     uint32_t* list;        // [No][Np*TPp] bucketed entries (partner << 16 | partner token); window x of a
                            // sequence starts at entry x*qpw*TPp of its region
-    float* dn;             // [nslot][No][TOp][128] f32 out: partial gradients (nslot = min(nwt, 8))
-    int nwt, qpw;          // partner windows in total (1, or a multiple of 8), partners per window
+    float* dn;             // [nslot][No][TOp][128] f32 out: partial gradients (nslot = min(nwt, BWD_WINS))
+    int nwt, qpw;          // partner windows in total (1, or a multiple of BWD_WINS), partners per window
     int win0, accumulate;  // gather launch: first window it covers; add to the partials instead of overwriting
 };
 

@@ -303,13 +303,13 @@ __global__ __launch_bounds__(INV_THREADS) void filip_invert_kernel(FilipBwdArgs 
 // keeps columns 8*l16..+7.  Index/weight loads are spread over the 16 lanes (16 partners or 16
 // list entries at a time) and broadcast inside the group; the 16 row gathers of a batch are all
 // in flight together.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void filip_gather_kernel(FilipBwdArgs p) {
+__device__ __forceinline__ void gather_block(const FilipBwdArgs& p, const int bid) {
     const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
     const int chunks = p.TOp >> 4;
     const int nslot = p.nwt < BWD_WINS ? p.nwt : BWD_WINS;
     const int share = nslot > 1 ? BWD_SHARE : 1;
     // block % 8 is the XCD: its low part picks the window, its high part which chunks of the own sequence
-    const int xcd = blockIdx.x % (nslot * share), blk = blockIdx.x / (nslot * share);
+    const int xcd = bid % (nslot * share), blk = bid / (nslot * share);
     const int slot = xcd % nslot, part = xcd / nslot;
     const int x = p.win0 + slot;
     const int cps = (chunks + share - 1) / share;   // chunks per sharing XCD
@@ -399,6 +399,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __builtin_nontemporal_store(v0, reinterpret_cast<f32x4v*>(out));
     __builtin_nontemporal_store(v1, reinterpret_cast<f32x4v*>(out) + 1);
 }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void filip_gather_kernel(FilipBwdArgs p) {
+    gather_block(p, (int)blockIdx.x);
+}
+// Both sides of the backward in one launch (the first `na` blocks are the A side's; `na` is a multiple of 8, so a
+// block's XCD is the same as in a launch of its own): one ramp and one tail instead of two.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void filip_gather2_kernel(FilipBwdArgs pa, FilipBwdArgs pb, int na) {
+    if ((int)blockIdx.x < na) gather_block(pa, (int)blockIdx.x);
+    else gather_block(pb, (int)blockIdx.x - na);
+}
 
 // out = sum of the nslot partial gradients (n4 float4 each); rows of padding tokens (never
 // written by the gather) are zero.
@@ -485,16 +494,15 @@ struct BwdTail {
     const float* tsign;
 };
 
-// gather launches of one side (four windows each), then the sum of the partials or the fused tail
-static int bwd_gather_side(FilipBwdArgs a, float* part, float* dn, const BwdTail& tail, hipStream_t st) {
+// blocks of one gather launch of a side
+static unsigned bwd_gather_blocks(const FilipBwdArgs& a) {
     const int nslot = a.nwt < BWD_WINS ? a.nwt : BWD_WINS;
     const int share = nslot > 1 ? BWD_SHARE : 1;
-    a.dn = a.nwt > 1 ? part : dn;
-    for (int w0 = 0; w0 < a.nwt; w0 += BWD_WINS) {
-        a.win0 = w0;
-        a.accumulate = w0 > 0;
-        hipLaunchKernelGGL(filip_gather_kernel, dim3(a.No * ((a.TOp / 16 + share - 1) / share) * nslot * share), dim3(256), 0, st, a);
-    }
+    return (unsigned)(a.No * ((a.TOp / 16 + share - 1) / share) * nslot * share);
+}
+// what follows the gathers of a side: the sum of the partials, or the fused tail
+static int bwd_finish_side(const FilipBwdArgs& a, float* part, float* dn, const BwdTail& tail, hipStream_t st) {
+    const int nslot = a.nwt < BWD_WINS ? a.nwt : BWD_WINS;
     const size_t n = (size_t)a.No * a.TOp * FD;
     if (tail.h)   // padding rows of the partials were never written: the mask words keep them out
         return filip_prep_bwd_launch(tail.h, a.dn, nslot, FD, (size_t)nslot * FD, a.nwt > 1 ? a.mwO : nullptr, a.No, tail.T, tail.d, tail.normalise,
@@ -503,6 +511,16 @@ static int bwd_gather_side(FilipBwdArgs a, float* part, float* dn, const BwdTail
         hipLaunchKernelGGL(filip_window_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (const float4*)part, n / 4, nslot,
                            (float4*)dn, a.mwO, a.TOp);
     return PCLIP_OK;
+}
+// gather launches of one side (four windows each), then the sum of the partials or the fused tail
+static int bwd_gather_side(FilipBwdArgs a, float* part, float* dn, const BwdTail& tail, hipStream_t st) {
+    a.dn = a.nwt > 1 ? part : dn;
+    for (int w0 = 0; w0 < a.nwt; w0 += BWD_WINS) {
+        a.win0 = w0;
+        a.accumulate = w0 > 0;
+        hipLaunchKernelGGL(filip_gather_kernel, dim3(bwd_gather_blocks(a)), dim3(256), 0, st, a);
+    }
+    return bwd_finish_side(a, part, dn, tail, st);
 }
 
 static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
@@ -563,15 +581,31 @@ static int filip_bwd_impl(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
     b.arg1 = argB; b.arg2 = argA; b.mut1 = mutB; b.mut2 = mutA; b.g1 = gBT; b.g2 = gAT; b.so = 1; b.sp = (size_t)Bc; b.gso = (size_t)Br; b.gsp = 1; b.t = t;
     b.icO = icB; b.icP = icA; b.seg = (int*)(w + L.segB); b.list = (uint32_t*)(w + L.listB); b.dn = nullptr;
     b.nwt = L.planB.nwt; b.qpw = L.planB.qpw; b.win0 = 0; b.accumulate = 0;
-    for (int side = 0; side < 2; ++side) {
-        if (!(side == 0 ? dnA : dnB)) continue;   // pclip_filip_sim_bwd: that side was not asked for
-        const FilipBwdArgs& u = side == 0 ? a : b;
+    auto invert = [&](const FilipBwdArgs& u) -> int {
         const size_t cap = (size_t)u.qpw * u.TPp;                       // entries of one window at most
         const int stage = cap <= INV_STAGE_MAX ? (int)cap : 0;
         const size_t lds = ((size_t)u.TOp + stage) * 4;
         static PclipLdsLimit lds_limit;
         if (int rc = pclip_ensure_lds(lds_limit, (const void*)filip_invert_kernel, lds, "filip_invert_kernel")) return rc;
         hipLaunchKernelGGL(filip_invert_kernel, dim3((unsigned)((size_t)u.No * u.nwt)), dim3(INV_THREADS), lds, st, u, stage);
+        return PCLIP_OK;
+    };
+    if (dnA && dnB && a.nwt <= BWD_WINS && b.nwt <= BWD_WINS && bwd_gather_blocks(a) % 8 == 0) {
+        // both sides wanted and one gather launch each: the two gathers share a launch
+        if (int rc = invert(a)) return rc;
+        if (int rc = invert(b)) return rc;
+        a.dn = a.nwt > 1 ? (float*)(w + L.partA) : dnA;
+        b.dn = b.nwt > 1 ? (float*)(w + L.partB) : dnB;
+        const unsigned na = bwd_gather_blocks(a), nb = bwd_gather_blocks(b);
+        hipLaunchKernelGGL(filip_gather2_kernel, dim3(na + nb), dim3(256), 0, st, a, b, (int)na);
+        if (int rc = bwd_finish_side(a, (float*)(w + L.partA), dnA, tailA, st)) return rc;
+        if (int rc = bwd_finish_side(b, (float*)(w + L.partB), dnB, tailB, st)) return rc;
+        return pclip_check_launch("filip backward (both sides)");
+    }
+    for (int side = 0; side < 2; ++side) {
+        if (!(side == 0 ? dnA : dnB)) continue;   // pclip_filip_sim_bwd: that side was not asked for
+        const FilipBwdArgs& u = side == 0 ? a : b;
+        if (int rc = invert(u)) return rc;
         if (int rc = bwd_gather_side(u, (float*)(w + (side == 0 ? L.partA : L.partB)), side == 0 ? dnA : dnB, side == 0 ? tailA : tailB, st))
             return rc;
         if (int rc = pclip_check_launch(side == 0 ? "filip backward (A side)" : "filip backward (B side)")) return rc;

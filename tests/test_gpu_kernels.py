@@ -455,6 +455,20 @@ def test_filip_backward_partner_windows(K):
     assert torch.isfinite(res[8]).all() and torch.isfinite(res[9]).all() and res[8].abs().sum() > 0
 
 
+def test_filip_backward_one_side_windowed(K):
+    """8 A sequences against 70 B sequences: the A side's partners (4.6 MB of B images) are cut into windows,
+    the B side's (0.5 MB of A images) are not, and both sides' gathers still share one launch."""
+    gen = torch.Generator().manual_seed(6)
+    Br, Bc, TA, TB, d = 8, 70, 256, 256, 128
+    hA, hB = torch.randn(Br, TA, d, generator=gen), torch.randn(Bc, TB, d, generator=gen)
+    lA, lB = torch.randint(1, TA + 1, (Br,), generator=gen), torch.randint(1, TB + 1, (Bc,), generator=gen)
+    mA = (torch.arange(TA)[None] < lA[:, None]).to(torch.uint8)
+    mB = (torch.arange(TB)[None] < lB[:, None]).to(torch.uint8)
+    gA, gB = torch.randn(Br, Bc, generator=gen), torch.randn(Br, Bc, generator=gen)
+    res = _check_routing_and_backward(K, hA, hB, mA, mB, torch.tensor(0.7), True, gA, gB, "one side windowed", rtol=4e-6)
+    assert torch.isfinite(res[8]).all() and torch.isfinite(res[9]).all()
+
+
 def _check_routing_and_backward(K, hA, hB, mA, mB, t, normalise, gA, gB, tag="", rtol=2e-6):
     """The two halves of backward parity, each tight: (1) every valid token's chosen partner attains
     the maximum of its row / column of the similarity tile to 2e-6 (the forward's tolerance);

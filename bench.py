@@ -254,9 +254,9 @@ def main():
             return clip_fused.run(dv["e_pep"], dv["e_rec"], t)
         return clip_sh.run(dv["e_pep"], dv["e_rec"], t)
 
-    def filip_step(ev=None):
+    def filip_step(ev=None, bev=None):
         if filip_fused is not None:
-            return filip_fused.run(dv["hA"], dv["hB"], dv["mA"], dv["mB"], t, sim_events=ev)
+            return filip_fused.run(dv["hA"], dv["hB"], dv["mA"], dv["mB"], t, sim_events=ev, bwd_events=bev)
         return filip_sh.run(dv["hA"], dv["hB"], dv["mA"], dv["mB"], t, sim_events=ev)
 
     def bracket(fn, steps):
@@ -281,12 +281,13 @@ def main():
     do_clip = args.workload in ("both", "clip")
     do_filip = args.workload in ("both", "filip")
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    bwd_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i, ev=True):
         if do_clip:
             clip_step()
         if do_filip:
-            filip_step(events[i] if ev else None)
+            filip_step(events[i] if ev else None, bwd_events[i] if ev else None)
 
     # Clock settle: an idle MI355X needs about 15 steps of this size to reach its steady clocks
     # (the score kernel goes from 0.82 to 0.73 ms over them).  A fixed number of untimed steps
@@ -297,6 +298,7 @@ def main():
         step(i, ev=False)
     total = bracket(lambda i: step(i), args.steps)
     sim_ms = statistics.mean(e0.elapsed_time(e1) for e0, e1 in events) if do_filip else None
+    bwd_ms = statistics.mean(e0.elapsed_time(e1) for e0, e1 in bwd_events) if do_filip and filip_fused is not None else None
 
     # per-workload brackets (same step counts), for the nested records
     t_clip = bracket(lambda i: clip_step(), args.steps) if do_clip else None
@@ -365,6 +367,9 @@ def main():
                 "ms_per_step": ms, "pairs_per_s": filip_bg / (ms * 1e-3), "scored_pairs_per_s": filip_bl * filip_bg * world / (ms * 1e-3),
                 "sim_kernel_ms": sim_ms, "sim_kernel_TFLOPs": roof["achieved"], "sim_kernel_mfma_frac": roof["frac"],
             }
+            if bwd_ms is not None:
+                # marks of mutual choices, inversions, both gathers and the prep backward (one C call)
+                workloads["filip"]["backward_ms"] = bwd_ms
             if full_ms is not None:
                 ff = 2.0 * D * (filip_bl * L) ** 2
                 workloads["filip_full_length_scores"] = {

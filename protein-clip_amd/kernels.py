@@ -418,9 +418,10 @@ class FilipStep:
         self.dt = e(1)
         self.bws = e(_lib.load().pclip_filip_bwd_fused_workspace_bytes(Br, TA, Bc, TB), dt=torch.uint8)
 
-    def run(self, hA, hB, mA8, mB8, t, sim_events=None):
+    def run(self, hA, hB, mA8, mB8, t, sim_events=None, bwd_events=None):
         """hA [Br,TA,d], hB [Bc,TB,d] f32; mA8/mB8 uint8 masks; t 1-element f32 tensor (all on
-        the GPU).  Returns (lossA, lossB, dhA, dhB, dt); the loss is (lossA + lossB) / 2."""
+        the GPU).  Returns (lossA, lossB, dhA, dhB, dt); the loss is (lossA + lossB) / 2.
+        ``bwd_events`` brackets the backward call (marks, inversions, gathers, prep backward)."""
         lib = _lib.load()
         Br, Bc, TA, TB, d = self.shape
         st = stream_of(hA)
@@ -436,8 +437,12 @@ class FilipStep:
         check(lib.pclip_filip_loss(ptr(self.simA), ptr(self.simB), Br, Bc, off, Bg, ptr(self.lse2), ptr(self.loss3), ptr(self.gA), ptr(self.gB),
                                    ptr(self.terms), st), "pclip_filip_loss")
         self.dt.zero_()
+        if bwd_events is not None:
+            bwd_events[0].record()
         check(lib.pclip_filip_bwd_fused(ptr(self.hnA), ptr(self.mwA), Br, TA, ptr(self.hnB), ptr(self.mwB), Bc, TB, ptr(t), ptr(self.simA),
                                         ptr(self.simB), ptr(self.argA), ptr(self.argB), ptr(self.gA), ptr(self.gB), ptr(hA), ptr(hB), d, 1,
                                         ptr(self.dhA), ptr(self.dhB), ptr(self.dt), ptr(self.bws), self.bws.numel(), st),
               "pclip_filip_bwd_fused")
+        if bwd_events is not None:
+            bwd_events[1].record()
         return self.loss3[1:2], self.loss3[2:3], self.dhA, self.dhB, self.dt

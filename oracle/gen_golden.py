@@ -198,6 +198,36 @@ def gen_filip(models, tuf):
                         lenA=_np(lA), lenB=_np(lB))
 
 
+def gen_filip_b256_bf16n(models, tuf):
+    """Benchmark-size instance on operands a bf16 matrix kernel sees EXACTLY: the tokens are normalised in f32 and
+    then rounded to bf16 (what ``pclip_filip_prep`` writes), and those rounded unit vectors go straight to the
+    reference's ``_filip_similarity_score`` (models.py:292-356).  All 2 x 65,536 scores and the loss are stored, so
+    the whole matrix can be compared at the tolerance of the small cases.  Inputs are regenerated from the seed."""
+    FIL = models.ExtendedFILIP
+    B, L, d = 256, 256, 128
+    g = torch.Generator().manual_seed(0)
+    hA = torch.randn(B, L, d, generator=g).to(torch.bfloat16).float()
+    hB = torch.randn(B, L, d, generator=g).to(torch.bfloat16).float()
+    lA = torch.randint(128, 257, (B,), generator=g)
+    lB = torch.randint(128, 257, (B,), generator=g)
+    mA = (torch.arange(L)[None] < lA[:, None]).long()
+    mB = (torch.arange(L)[None] < lB[:, None]).long()
+    nA = (hA / hA.norm(dim=-1, keepdim=True)).to(torch.bfloat16).float()
+    nB = (hB / hB.norm(dim=-1, keepdim=True)).to(torch.bfloat16).float()
+    t = torch.tensor(1.0)
+    sA = torch.empty(B, B); sB = torch.empty(B, B)
+    blk = 16
+    with torch.no_grad():
+        for i0 in range(0, B, blk):
+            for j0 in range(0, B, blk):
+                a_, b_ = FIL._filip_similarity_score(nA[i0:i0+blk], nB[j0:j0+blk], mA[i0:i0+blk], mB[j0:j0+blk], t)
+                sA[i0:i0+blk, j0:j0+blk] = a_; sB[i0:i0+blk, j0:j0+blk] = b_
+            print("filip B256 bf16n block row", i0, flush=True)
+        loss = tuf._compute_loss(sA, sB)
+    np.savez_compressed(os.path.join(OUT, "filip_b256_l256_bf16n.npz"), sim_A=_np(sA), sim_B=_np(sB), loss=_np(loss),
+                        lenA=_np(lA), lenB=_np(lB))
+
+
 def gen_loops(models, tu, tuf):
     """Two epochs of the reference's own train/evaluate loops on a tiny randomly initialised
     ESM-2 (hidden 32, 2 layers) and 8 synthetic sequence pairs: pins the loop order
@@ -290,6 +320,54 @@ def gen_topk(models, tu):
         json.dump(out, f, indent=1)
 
 
+def gen_train_gc(models, tu):
+    """The reference's own ``train_gc`` (training_utils.py:92-155) run through the replaying stand-in for
+    ``grad_cache.functional.cached`` above, on the tiny model of the loop traces: 20 pairs in sub-batches of 4
+    with ``accumulated_batches=2`` — two big batches of 8 and one trailing sub-batch that is encoded and dropped
+    (:134) — for two epochs.  Stored: the loss of every big batch (:137), the epoch means the function returns
+    (:155), and temperature and head parameters after each epoch, which pin the order of
+    ``scaler.step / update / zero_grad`` (:151-153)."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from protein_clip_amd import synthetic as S
+    from torch.utils.data import DataLoader
+    tok = S.make_tokenizer()
+    data = S.PairDataset(20, pep_len=(5, 12), rec_len=(10, 30), seed=11)
+    torch.manual_seed(42)
+    esm = S.make_esm(32, 2, 4)
+    for prm in esm.parameters():
+        prm.requires_grad = False
+    model = models.ExtendedCLIP(32, 16, 2, 2, 0.0, esm)
+    loader = DataLoader(data, batch_size=4, shuffle=False, drop_last=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    scaler = torch.cuda.amp.GradScaler(enabled=False)
+    seen = []
+    inner = tu._contrastive_loss_gc
+
+    def recording_loss(x, y):
+        loss = inner(x, y)
+        seen.append(float(loss.item()))
+        return loss
+    tu._contrastive_loss_gc = recording_loss
+    out = {"peptides": data.pep, "receptors": data.rec, "batch_size": 4, "accumulated_batches": 2, "seed": 42, "lr": 1e-3,
+           "esm": {"hidden": 32, "layers": 2, "heads": 4},
+           "head": {"input_dim": 32, "embedding_dim": 16, "h1": 2, "h2": 2, "dropout": 0.0}, "epochs": []}
+    arrays = {}
+    try:
+        for ep in range(2):
+            seen.clear()
+            mean = tu.train_gc(model, loader, tok, opt, scaler, "cpu", accumulated_batches=2)
+            out["epochs"].append({"mean": float(mean), "big_batch_losses": list(seen), "temperature": float(model.temperature.item())})
+            for name, prm in model.named_parameters():
+                if prm.requires_grad:
+                    arrays[f"epoch{ep}/{name}"] = _np(prm).copy()   # a snapshot: the optimizer updates in place
+    finally:
+        tu._contrastive_loss_gc = inner
+    with open(os.path.join(OUT, "train_gc_trace.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    np.savez_compressed(os.path.join(OUT, "train_gc_params.npz"), **arrays)
+
+
 def gen_head(models):
     """The reference's ``Encoder`` (models.py:7-90) with a stand-in trunk that returns fixed hidden
     states: everything after the per-residue network — masked mean, ``embedding_ffn``, normalise and
@@ -372,6 +450,14 @@ def main():
         gen_head(models)
         print("head fixtures written", flush=True)
         return
+    if "--b256-bf16n-only" in sys.argv:
+        gen_filip_b256_bf16n(models, tuf)
+        print("bf16n benchmark-size fixture written", flush=True)
+        return
+    if "--train-gc-only" in sys.argv:
+        gen_train_gc(models, tu)
+        print("train_gc trace written", flush=True)
+        return
     if "--ties-topk-only" in sys.argv:
         gen_ties(models, tuf)
         gen_topk(models, tu)
@@ -380,10 +466,12 @@ def main():
     if "--loops-only" not in sys.argv:
         gen_ties(models, tuf)
         gen_topk(models, tu)
+        gen_train_gc(models, tu)
         gen_head(models)
         gen_clip(tu)
         print("clip goldens written", flush=True)
         gen_filip(models, tuf)
+        gen_filip_b256_bf16n(models, tuf)
         print("filip goldens written", flush=True)
     gen_loops(models, tu, tuf)
     print("loop traces written", flush=True)

@@ -17,6 +17,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def is_port_clash(exc) -> bool:
+    """True when a multi-process rendezvous failed because the port picked for it was taken in the meantime
+    (EADDRINUSE, errno 98): the ONLY failure the two-rank fixtures try again on a fresh port; anything else a
+    rank raises is a real failure and surfaces on the first attempt."""
+    text = repr(exc) + str(exc)
+    return any(m in text for m in ("Address already in use", "EADDRINUSE", "errno: 98", "Errno 98", "address already in use"))
+
+
 def load_cases(name):
     """Return {case_key: {field: torch tensor}} from a grouped ``.npz`` (keys 'case/field')."""
     z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)

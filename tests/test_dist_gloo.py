@@ -6,6 +6,8 @@ import os
 import sys
 
 import pytest
+
+from conftest import is_port_clash
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -73,9 +75,9 @@ def two_rank_results(tmp_path_factory):
             mp.start_processes(_worker, args=(port, out_dir), nprocs=WORLD, join=True, start_method="spawn")
             break
         except Exception as e:
-            print(f"two-rank attempt {attempt} failed: {e!r}", file=sys.stderr)
-            if attempt == 2:
+            if attempt == 2 or not is_port_clash(e):   # only a lost race for the port is worth another attempt
                 raise
+            print(f"two-rank attempt {attempt}: port {port} was taken, trying another ({e!r})", file=sys.stderr)
     return [torch.load(os.path.join(out_dir, f"rank{r}.pt"), weights_only=True) for r in range(WORLD)]
 
 

@@ -151,6 +151,15 @@ def test_big_batch_trainer_equals_one_big_batch(env):
             torch.testing.assert_close(p1, p2, rtol=2e-4, atol=2e-6, msg=lambda m: f"{n1}: {m}")
 
 
+def test_big_batch_trainer_matches_the_reference_train_gc(env):
+    """``train_gc`` on the HIP operators against what the REFERENCE's own ``train_gc`` (training_utils.py:92-155, run
+    through a replaying stand-in for ``grad_cache.functional.cached`` by oracle/gen_golden.py) returned and left
+    behind: every big-batch loss, the epoch means, temperature and all head parameters after each of two epochs;
+    five sub-batches with two per big batch, so the trailing one is encoded and dropped as in the reference."""
+    from test_oracle_golden import run_train_gc_against_trace
+    run_train_gc_against_trace("cuda", 2e-4, 2e-2)
+
+
 def test_big_batch_trainer_replays_dropout(env):
     """With dropout on, the second (graph) pass of a sub-batch must see the first pass's masks:
     the representation recomputed in the replay equals the cached one."""

@@ -102,6 +102,29 @@ def test_filip_benchmark_size_rows():
     close(O.filip_loss(g["sim_A"], g["sim_B"]), g["loss"], 1e-6, 1e-6)
 
 
+def test_filip_benchmark_size_rows_bf16_exact_operands():
+    """The second benchmark-size fixture: tokens normalised, THEN rounded to bf16, fed to the reference's score
+    function as they are (what a bf16 matrix kernel computes on exactly).  A slice from regenerated inputs."""
+    g = load_flat("filip_b256_l256_bf16n.npz")
+    B, L, d = 256, 256, 128
+    gen = torch.Generator().manual_seed(0)
+    hA = O.bf16_round(torch.randn(B, L, d, generator=gen))
+    hB = O.bf16_round(torch.randn(B, L, d, generator=gen))
+    lA = torch.randint(128, 257, (B,), generator=gen)
+    lB = torch.randint(128, 257, (B,), generator=gen)
+    assert torch.equal(lA, g["lenA"]) and torch.equal(lB, g["lenB"])
+    mA, mB = O.right_padded_masks(lA, L), O.right_padded_masks(lB, L)
+    nA = O.bf16_round(hA[100:108] / hA[100:108].norm(dim=-1, keepdim=True))   # the generator's expression (torch's norm)
+    nB = O.bf16_round(hB[64:96] / hB[64:96].norm(dim=-1, keepdim=True))
+    sA, sB = O.filip_similarity(nA, nB, mA[100:108], mB[64:96], torch.tensor(1.0), block=8)
+    close(sA, g["sim_A"][100:108, 64:96], 1e-6, 1e-6)
+    close(sB, g["sim_B"][100:108, 64:96], 1e-6, 1e-6)
+    close(O.filip_loss(g["sim_A"], g["sim_B"]), g["loss"], 1e-6, 1e-6)
+    # rounding the unit vectors to bf16 moves a score by up to a few 1e-4: the two fixtures differ by that much
+    g32 = load_flat("filip_b256_l256.npz")
+    assert 1e-5 < (g["sim_A"] - g32["sim_A"]).abs().max() < 2e-3
+
+
 def test_filip_exact_ties_split_evenly_like_the_reference():
     """Duplicated tokens (exact ties of the max): the oracle's gradient equals the reference's
     even split among the tied tokens, element by element."""
@@ -147,6 +170,95 @@ def test_topk_eval_host_logic_against_the_reference_ranks():
         for k in range(8):
             got = training_utils.eval_gc_allrec_onepep(model, loader, "cpu", tok, agg_batches=want["agg_batches"], k=k)
             assert got == want["ranks"][str(k)], (k, got, want["ranks"][str(k)], want["diag"][str(k)])
+    finally:
+        ops._hip_kernels = real
+
+
+def _train_gc_trace():
+    import json
+    import os
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "train_gc_trace.json")) as f:
+        want = json.load(f)
+    z = np.load(os.path.join(root, "tests", "golden", "train_gc_params.npz"), allow_pickle=False)
+    return want, {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def run_train_gc_against_trace(device, loss_tol, param_rel):
+    """Shared by the CPU (stand-in provider) and GPU tests: ``train_gc`` on the pairs, model and optimizer of
+    ``tests/golden/train_gc_trace.json``, which holds what the REFERENCE's ``train_gc``
+    (training_utils.py:92-155) returned and left behind: the loss of every big batch, the epoch means,
+    and temperature and head parameters after each epoch (20 pairs, sub-batches of 4, two per big batch,
+    so the fifth sub-batch of an epoch is encoded and dropped)."""
+    from torch.utils.data import DataLoader
+    from protein_clip_amd import synthetic as S
+    from protein_clip_amd.modules import models, training_utils
+
+    class Pairs(torch.utils.data.Dataset):
+        def __init__(self, pep, rec):
+            self.pep, self.rec = pep, rec
+
+        def __len__(self):
+            return len(self.pep)
+
+        def __getitem__(self, i):
+            return self.pep[i], self.rec[i]
+
+    want, params = _train_gc_trace()
+    tok = S.make_tokenizer()
+    torch.manual_seed(want["seed"])
+    esm = S.make_esm(want["esm"]["hidden"], want["esm"]["layers"], want["esm"]["heads"])
+    for prm in esm.parameters():
+        prm.requires_grad = False
+    h = want["head"]
+    model = models.ExtendedCLIP(h["input_dim"], h["embedding_dim"], h["h1"], h["h2"], h["dropout"], esm).to(device)
+    start = {n: p.detach().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
+    loader = DataLoader(Pairs(want["peptides"], want["receptors"]), batch_size=want["batch_size"], shuffle=False, drop_last=True)
+    opt = torch.optim.Adam(model.parameters(), lr=want["lr"])
+    scaler = torch.amp.GradScaler("cuda", enabled=False)
+    seen = []
+    inner = training_utils._contrastive_loss_gc
+
+    def recording(x, y, group=None):
+        loss = inner(x, y, group=group)
+        seen.append(float(loss.item()))
+        return loss
+    training_utils._contrastive_loss_gc = recording
+    try:
+        for ep, w in enumerate(want["epochs"]):
+            seen.clear()
+            mean = training_utils.train_gc(model, loader, tok, opt, scaler, device, accumulated_batches=want["accumulated_batches"])
+            assert len(seen) == len(w["big_batch_losses"]) == 2      # the trailing fifth sub-batch formed no batch
+            for got, ref in zip(seen, w["big_batch_losses"]):
+                assert abs(got - ref) < loss_tol, (ep, seen, w)
+            assert abs(mean - w["mean"]) < loss_tol
+            assert abs(model.temperature.item() - w["temperature"]) < loss_tol
+            # parameters: the distance travelled from the start is what the steps produced; compare that
+            num = den = 0.0
+            for n, p in model.named_parameters():
+                if p.requires_grad:
+                    ref = params[f"epoch{ep}/{n}"]
+                    num += float((p.detach().cpu() - ref).pow(2).sum())
+                    den += float((ref - start[n]).pow(2).sum())
+            assert den > 0 and (num / den) ** 0.5 < param_rel, (ep, (num / den) ** 0.5)
+    finally:
+        training_utils._contrastive_loss_gc = inner
+
+
+def test_train_gc_host_logic_against_the_reference_trace():
+    """The big-batch trainer's host logic (grouping of sub-batches, the dropped trailing sub-batch, replay, order of
+    step / update / zero_grad, epoch mean) against the reference's own ``train_gc``; compute through the CPU
+    stand-in provider."""
+    import cpu_provider as P
+    from protein_clip_amd import ops
+    want, _ = _train_gc_trace()
+    for w in want["epochs"]:
+        assert abs(sum(w["big_batch_losses"]) / len(w["big_batch_losses"]) - w["mean"]) < 1e-6   # training_utils.py:155
+    real = ops._hip_kernels
+    ops._hip_kernels = P
+    try:
+        run_train_gc_against_trace("cpu", 2e-5, 1e-4)   # measured: passes at 1e-5
     finally:
         ops._hip_kernels = real
 

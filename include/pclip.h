@@ -102,7 +102,14 @@ int pclip_clip_bwd(const float* X_own, const float* Y_own, const float* X_all, c
  * (dt is overwritten here).  Up to B = 512 the step is ONE persistent launch whose workgroups
  * meet at grid-wide barriers; that form is only taken when the CURRENT device keeps the whole grid
  * resident (a partition with few compute units takes the separate launches instead), so size the
- * workspace with the device current on which the step will run. */
+ * workspace with the device current on which the step will run.
+ * The one-launch form (also behind pclip_clip_loss_grad and pclip_clip_step_noalloc) needs its grid
+ * resident as a whole, so two of them must not share a GPU: inside one process the library chains
+ * such launches across streams (the new stream waits for the work enqueued on the stream used
+ * last; streams under graph capture are left alone), ACROSS PROCESSES IT CANNOT — give the step a
+ * GPU of its own (one process per GPU).  A launch whose barrier cannot complete gives up after
+ * about half a second and fails visibly: loss, every gradient and dt are NaN, and so are those of
+ * every later one-launch step on that GPU until pclip_clip_step_sync_reset(). */
 size_t pclip_clip_step_workspace_bytes(int B, int d);
 int pclip_clip_step(const float* e_pep, const float* e_rec, const float* t, int B, int d,
                     float* loss, float* de_pep, float* de_rec, float* dt,
@@ -116,13 +123,26 @@ size_t pclip_clip_loss_grad_workspace_bytes(int B, int d);
 int pclip_clip_loss_grad(const float* x, const float* y, int B, int d, float* loss, float* dx, float* dy,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* Diagnostics of the one-launch form's barrier (no counterpart in the reference).
+ *   pclip_clip_step_sync_status: *gave_up = 1 when a barrier wait on the current device has given up
+ *     since the last reset (results were NaN from then on).  SYNCHRONISES the device.
+ *   pclip_clip_step_sync_reset: clears the barrier words of the current device (enqueued on `stream`);
+ *     call it only while no one-launch step is in flight on that GPU.
+ *   pclip_clip_step_selftest_giveup(on): while on, every one-launch step waits for one arrival more
+ *     than its grid has, i.e. takes the give-up path (tests of the visible failure). */
+int pclip_clip_step_sync_status(int* gave_up);
+int pclip_clip_step_sync_reset(void* stream);
+int pclip_clip_step_selftest_giveup(int on);
+
 /* The same step without a workspace argument.  It has no counterpart in the reference: it exists
  * for callers that cannot allocate device memory or size a workspace (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  The scratch of the step lives in
  * a fixed device array inside the library (pclip_clip_step_noalloc_max_bytes() = 10 MiB per GPU,
  * held until the process ends), which covers B <= 1024 at d = 128; larger problems are rejected
  * with PCLIP_EINVAL.  No call allocates or frees.  The first call on a device looks the array's
- * address up (once per device, with that device current).  All calls on one GPU share that GPU's
+ * address up (once per device, with that device current) and asks the runtime for the kernel's
+ * occupancy: make one eager call per device before capturing the step into a HIP graph, where it
+ * then is a single kernel node (B <= 512).  All calls on one GPU share that GPU's
  * array: calls that overlap in time on one GPU (two streams, two threads) race; calls on one stream
  * are safe.  Results equal pclip_clip_step's. */
 size_t pclip_clip_step_noalloc_max_bytes(void);

@@ -30,6 +30,9 @@ _SIGNATURES = {
     "pclip_clip_step": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "pclip_clip_loss_grad_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pclip_clip_loss_grad": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "pclip_clip_step_sync_status": (c_int, [_P]),
+    "pclip_clip_step_sync_reset": (c_int, [_P]),
+    "pclip_clip_step_selftest_giveup": (c_int, [c_int]),
     "pclip_clip_step_noalloc_max_bytes": (c_size_t, []),
     "pclip_clip_step_noalloc": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "pclip_rowce_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),

@@ -463,7 +463,7 @@ extern "C" int pclip_clip_step_noalloc(const float* e_pep, const float* e_rec, c
     void* ws = nullptr;
     if (int rc = clip_scratch_of_current_device(&ws)) return rc;
     // every buffer of the step inside the scratch is written before it is read (dt is cleared by the
-    // first kernel, the barrier counter of the one-launch form by a memset node in front of it), so
-    // nothing else has to be zeroed between calls
+    // first kernel; the barrier words of the one-launch form live outside the scratch and clear
+    // themselves), so nothing has to be zeroed between calls
     return pclip_clip_step(e_pep, e_rec, t, B, d, loss, de_pep, de_rec, dt, ws, CLIP_NOALLOC_SCRATCH_BYTES, stream);
 }

@@ -20,6 +20,16 @@
 // (sc1), every storing wave drains its stores before the workgroup's one arrival on the barrier
 // counter: no cache-wide release / acquire fences (several us per barrier here), and no
 // assumption about where a workgroup runs.
+//
+// The barrier words live in a small device array of this code object (one copy per GPU, zero when
+// the code object is loaded): [0] arrivals, [1] a sticky flag set when a wait gave up, [2]
+// departures.  The workgroup that departs last clears [0] and [2], so a launch needs no memset
+// in front of it.  A grid barrier only completes when the whole grid is resident; launches of
+// this kernel from different streams of one process are therefore chained on the host (an
+// event from the stream used last), and a launch that still cannot complete (another process
+// filling the GPU with a barrier kernel of its own) gives up after about half a second, sets
+// the sticky flag and writes NaN to the loss and every gradient — as does every later launch
+// on that GPU until pclip_clip_step_sync_reset().
 #include "pclip_common.h"
 
 #define CS_D 128            // padded contraction width
@@ -32,7 +42,9 @@ struct ClipStepArgs {
     int B, d, nT;
     int raw;                  // 1: e_pep / e_rec are raw head outputs (normalise, scale, Jacobian, dt); 0: they are x, y as the towers return them
     float scale;              // 0.5 / B
-    unsigned* counter;        // [0] arrivals (zeroed by the launcher), [1] set when a wait gave up
+    unsigned* counter;        // [0] arrivals, [1] sticky: a wait gave up, [2] departures (the last one clears [0] and [2])
+    unsigned* stamps;         // diagnostic build only: the head of the caller's workspace
+    unsigned extra;           // added to the arrivals a barrier waits for (0; 1 in the self-test of the give-up path)
     float2* part_row;         // [nT (tile column)][B]  (max, sum) of row i over the tile's 32 columns
     float2* part_col;         // [nT (tile row)][B]     (max, sum) of column j over the tile's 32 rows
     float* diag;              // [B] S_ii
@@ -57,7 +69,7 @@ __device__ __forceinline__ float2 ld_f32x2(const float* p) {
 // All workgroups of the grid (resident together: the launcher keeps the grid within the CU
 // count) meet here.  What a workgroup stored with the helpers above before the barrier, any
 // workgroup reads with them after it.  `target` = workgroups x barriers passed so far.
-__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target, unsigned long long* stamp = nullptr) {
+__device__ __forceinline__ bool grid_barrier(unsigned* counter, unsigned target, int* gave_up_lds, unsigned long long* stamp = nullptr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -65,15 +77,20 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target,
         const unsigned before = __hip_atomic_fetch_add((gu32*)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (stamp) { stamp[1] = __builtin_amdgcn_s_memrealtime() + (before & 0); stamp[2] = before; }
         unsigned spins = 0;
-        while (__hip_atomic_load((gu32*)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        for (;;) {   // arrivals and the sticky flag are one 8-byte word: the flag costs no load of its own
+            const unsigned long long v = __hip_atomic_load((gu64*)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) != 0u) { *gave_up_lds = 1; break; }   // a wait gave up, in this launch or an earlier one
+            if ((unsigned)v >= target) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) {   // never in a healthy run: leave a mark instead of hanging
+            if (++spins > (1u << 23)) {   // never in a healthy run (about half a second): leave a sticky mark instead of hanging
                 __hip_atomic_store((gu32*)(counter + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *gave_up_lds = 1;
                 break;
             }
         }
     }
     __syncthreads();
+    return *gave_up_lds != 0;
 }
 
 // Sum over each group of 16 consecutive lanes (every lane of a group gets it).
@@ -109,13 +126,28 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ e0, int r0,
 
 #ifdef CLIP_STAMPS   // diagnostic build: 100-MHz time stamps of every workgroup, 16 per workgroup, after the counter block
 #define CS_COUNTER_BYTES (256 + 256 * 16 * 8)
-#define CSTAMP_AT(k) (reinterpret_cast<unsigned long long*>(p.counter) + 32 + blockIdx.x * 16 + (k))
+#define CSTAMP_AT(k) (reinterpret_cast<unsigned long long*>(p.stamps) + 32 + blockIdx.x * 16 + (k))
 #define CSTAMP(k) do { if (threadIdx.x == 0) *CSTAMP_AT(k) = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CS_COUNTER_BYTES 256
 #define CSTAMP_AT(k) nullptr
 #define CSTAMP(k) do {} while (0)
 #endif
+
+// The visible failure: NaN in the loss, in every gradient row this workgroup would have written, and in dt.
+__device__ __forceinline__ void clip_step_poison(const ClipStepArgs& p, int tid, unsigned nwg) {
+    const float nan = __int_as_float(0x7FC00000);
+    const int lane = tid & 63, w = tid >> 6, l = lane & 15, g = lane >> 4;
+    for (int row2 = (4 * w + g) * (int)nwg + (int)blockIdx.x; row2 < 2 * p.B; row2 += 16 * (int)nwg) {
+        const bool rec = row2 >= p.B;
+        float* der = (rec ? p.de_rec : p.de_pep) + (size_t)(rec ? row2 - p.B : row2) * p.d;
+        for (int col = l; col < p.d; col += 16) der[col] = nan;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        p.loss[0] = nan;
+        if (p.raw) p.dt[0] = nan;
+    }
+}
 
 __global__ __launch_bounds__(256) void clip_step_kernel(ClipStepArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -125,6 +157,7 @@ __global__ __launch_bounds__(256) void clip_step_kernel(ClipStepArgs p) {
     float* gT = red + 32 * CS_LD;          // [32][33]     G[j][i]
     float* lseR = gT + 32 * 33;            // [32]
     float* lseC = lseR + 32;               // [32]
+    int* gave_up = reinterpret_cast<int*>(lseC + 32);   // [1] a barrier wait of this workgroup gave up
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int it = blockIdx.x % p.nT, jt = blockIdx.x / p.nT;
@@ -133,6 +166,9 @@ __global__ __launch_bounds__(256) void clip_step_kernel(ClipStepArgs p) {
     const unsigned nwg = gridDim.x;
 
     if (blockIdx.x == 0 && tid == 0 && p.raw) st_f32(p.dt, 0.f);   // phase C adds into it, two barriers from here
+    // (a wait that gave up on this GPU earlier left a sticky flag: the barrier words are then in no known state, and the
+    // first barrier of every later launch sees the flag and fails visibly)
+    if (tid == 0) *gave_up = 0;
 
     // ---- phase A --------------------------------------------------------------------------
     CSTAMP(0);
@@ -195,7 +231,8 @@ __global__ __launch_bounds__(256) void clip_step_kernel(ClipStepArgs p) {
         if (((c >> 2) & 1) == h && ivalid) st_f32(p.diag + i0 + c, dv);
     }
     CSTAMP(3);
-    grid_barrier(p.counter, nwg, CSTAMP_AT(10));
+    // (a wait that gives up here is noticed behind the second barrier: phase B then runs on garbage, which stays inside the scratch)
+    grid_barrier(p.counter, nwg + p.extra, gave_up, CSTAMP_AT(10));
     CSTAMP(4);
 
     // ---- phase B --------------------------------------------------------------------------
@@ -276,8 +313,16 @@ __global__ __launch_bounds__(256) void clip_step_kernel(ClipStepArgs p) {
         }
     }
     CSTAMP(6);
-    grid_barrier(p.counter, 2 * nwg, CSTAMP_AT(13));
+    const bool poisoned = grid_barrier(p.counter, 2 * nwg + p.extra, gave_up, CSTAMP_AT(13));   // the flag set at either barrier
     CSTAMP(7);
+    if (poisoned) {   // uniform over the workgroup
+        clip_step_poison(p, tid, nwg);
+        return;
+    }
+    // Every workgroup has left both waits once `nwg` departures are counted: the last one clears the words for the
+    // next launch.  The atomic is issued here and its result used at the end of the kernel.
+    unsigned departed = 0;
+    if (tid == 0) departed = __hip_atomic_fetch_add((gu32*)(p.counter + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- phase C --------------------------------------------------------------------------
     // sixteen lanes per row of the two towers (columns 4 l .. 4 l + 3 and 64 + 4 l .. of lane l), sixteen
@@ -350,29 +395,57 @@ __global__ __launch_bounds__(256) void clip_step_kernel(ClipStepArgs p) {
         if (tid == 0) p.loss[0] = ((lseC[0] + lseC[1]) + (lseC[2] + lseC[3])) * p.scale;
     }
     CSTAMP(9);
+    if (tid == 0 && departed == nwg - 1) {
+        __hip_atomic_store((gu32*)p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((gu32*)(p.counter + 2), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- host side -------------------------------------------------------------------------
-#define CS_LDS_BYTES ((size_t)(3 * 32 * CS_LD + 32 * 33 + 64) * sizeof(float))
+#define CS_LDS_BYTES ((size_t)(3 * 32 * CS_LD + 32 * 33 + 64 + 4) * sizeof(float))
 
-// Workgroups of this kernel that the current device keeps resident at once (the grid barrier needs the whole
-// grid resident: a device partition with few CUs takes the separate launches instead).  Asked once per device.
-static int clip_step_resident_capacity() {
-    static std::mutex mu;
-    static int cap[PCLIP_MAX_DEVICES];
+// The barrier words of the current device's copy of this code object.
+static __device__ __align__(256) unsigned clip_sync_words[64];
+
+// Per device: the workgroups of this kernel that the device keeps resident at once (the grid barrier needs the whole
+// grid resident: a device partition with few CUs takes the separate launches instead), the device address of the
+// barrier words, and the stream the kernel was launched on last.  Asked once per device.
+struct ClipStepDevice {
+    int cap = 0;                    // 0: not asked yet, -1: the one-launch form is unavailable
+    unsigned* sync = nullptr;
+    bool launched = false;          // a launch outside stream capture has happened; `last` is its stream
+    hipStream_t last = nullptr;
+    hipEvent_t chain = nullptr;     // made with the rest of this record, so that no launch ever creates anything
+};
+static std::mutex g_cs_mu;
+static ClipStepDevice g_cs_dev[PCLIP_MAX_DEVICES];
+static int g_cs_selftest_extra = 0;   // pclip_clip_step_selftest_giveup
+
+static ClipStepDevice* clip_step_device_locked() {   // g_cs_mu held
     static PclipLdsLimit lim;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PCLIP_MAX_DEVICES) return 0;
-    std::lock_guard<std::mutex> lock(mu);
-    if (cap[dev] == 0) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PCLIP_MAX_DEVICES) return nullptr;
+    ClipStepDevice& D = g_cs_dev[dev];
+    if (D.cap == 0) {
         int cus = 0, per_cu = 0;
-        cap[dev] = -1;
+        void* sp = nullptr;
+        D.cap = -1;
         if (pclip_ensure_lds(lim, (const void*)clip_step_kernel, CS_LDS_BYTES, "clip_step_kernel") == PCLIP_OK &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)clip_step_kernel, 256, CS_LDS_BYTES) == hipSuccess && cus * per_cu > 0)
-            cap[dev] = cus * per_cu;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)clip_step_kernel, 256, CS_LDS_BYTES) == hipSuccess && cus * per_cu > 0 &&
+            hipGetSymbolAddress(&sp, HIP_SYMBOL(clip_sync_words)) == hipSuccess && sp &&
+            hipEventCreateWithFlags(&D.chain, hipEventDisableTiming) == hipSuccess) {
+            D.cap = cus * per_cu;
+            D.sync = (unsigned*)sp;
+        }
+        (void)hipGetLastError();
     }
-    return cap[dev] > 0 ? cap[dev] : 0;
+    return &D;
+}
+static int clip_step_resident_capacity() {
+    std::lock_guard<std::mutex> lock(g_cs_mu);
+    const ClipStepDevice* D = clip_step_device_locked();
+    return D && D->cap > 0 ? D->cap : 0;
 }
 
 bool clip_step_fused_ok(int B, int d) {
@@ -412,7 +485,62 @@ int clip_step_fused_launch(const float* e_pep, const float* e_rec, const float* 
     a.diag = (float*)(w + L.diag); a.lse_row = (float*)(w + L.lse_row); a.lse_col = (float*)(w + L.lse_col);
     a.slab_x = (float*)(w + L.slab_x); a.slab_y = (float*)(w + L.slab_y);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(a.counter, 0, 256, st) != hipSuccess) return pclip_fail(PCLIP_ELAUNCH, "clip_step: cannot clear the barrier counter");
+    std::lock_guard<std::mutex> lock(g_cs_mu);
+    ClipStepDevice* D = clip_step_device_locked();
+    if (!D || D->cap <= 0 || !D->sync) return pclip_fail(PCLIP_ELAUNCH, "clip_step: the one-launch form is not available on the current device");
+    a.counter = D->sync;
+    a.stamps = (unsigned*)(w + L.counter);
+    a.extra = (unsigned)g_cs_selftest_extra;
+    // Two grids that wait at barriers must not share the GPU: each could hold part of the compute units and wait for
+    // the rest for ever.  Launches on one stream follow each other anyway; when the stream changes, the new stream
+    // first waits for everything enqueued so far on the one used last.  A stream under capture is left alone (an
+    // event wait would pull the other stream into the capture): replaying such a graph beside other one-launch
+    // steps of the same GPU is the caller's to avoid.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap == hipStreamCaptureStatusNone) {
+        if (D->launched && D->last != st) {
+            // the stream used last may have been destroyed since: its work then completes on its own, nothing to wait for
+            if (hipEventRecord(D->chain, D->last) == hipSuccess) {
+                if (hipStreamWaitEvent(st, D->chain, 0) != hipSuccess) return pclip_fail(PCLIP_ELAUNCH, "clip_step: hipStreamWaitEvent failed");
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        D->launched = true;
+        D->last = st;
+    }
     hipLaunchKernelGGL(clip_step_kernel, dim3(a.nT * a.nT), dim3(256), CS_LDS_BYTES, st, a);   // the LDS limit was raised by the capacity query
     return pclip_check_launch("clip_step_kernel");
+}
+
+// ---- diagnostics of the barrier words -----------------------------------------------------
+extern "C" int pclip_clip_step_sync_status(int* gave_up) {
+    PCLIP_REQUIRE(gave_up, "clip_step_sync_status: null pointer");
+    unsigned* sync = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_cs_mu);
+        const ClipStepDevice* D = clip_step_device_locked();
+        if (!D || !D->sync) { *gave_up = 0; return PCLIP_OK; }   // the one-launch form never runs on this device
+        sync = D->sync;
+    }
+    unsigned words[4] = {0, 0, 0, 0};
+    if (hipMemcpy(words, sync, sizeof(words), hipMemcpyDeviceToHost) != hipSuccess)
+        return pclip_fail(PCLIP_ELAUNCH, "clip_step_sync_status: cannot read the barrier words");
+    *gave_up = words[1] != 0u;
+    return PCLIP_OK;
+}
+
+extern "C" int pclip_clip_step_sync_reset(void* stream) {
+    std::lock_guard<std::mutex> lock(g_cs_mu);
+    const ClipStepDevice* D = clip_step_device_locked();
+    if (!D || !D->sync) return PCLIP_OK;
+    if (hipMemsetAsync(D->sync, 0, 256, (hipStream_t)stream) != hipSuccess) return pclip_fail(PCLIP_ELAUNCH, "clip_step_sync_reset: memset failed");
+    return PCLIP_OK;
+}
+
+extern "C" int pclip_clip_step_selftest_giveup(int on) {
+    std::lock_guard<std::mutex> lock(g_cs_mu);
+    g_cs_selftest_extra = on ? 1 : 0;
+    return PCLIP_OK;
 }

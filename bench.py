@@ -13,7 +13,8 @@ raw head outputs to their gradients, inputs resident in HBM:
             two row InfoNCE losses -> backward.
 ``value`` = protein pairs of both global batches per second of whole-job time (max over
 ranks).  The per-workload numbers and rooflines are in ``workloads``.  Rank 0 prints ONE JSON
-line.  The CPU baseline (N=1 only) times the repository's CPU oracle on a bounded sample.
+line.  The CPU baseline (N=1 only) times the repository's CPU oracle on the same inputs: the
+whole step of both workloads on all host threads (about half a minute), one-thread figures beside it.
 """
 import argparse
 import json
@@ -71,34 +72,59 @@ def make_inputs(rank, clip_bl, filip_bl, device):
 
 
 def cpu_baseline(cpu, clip_b, filip_b):
-    """Oracle (PyTorch-CPU restatement of the reference path) on the host cores: CLIP at the
-    full batch; FILIP on the first 64x64 block of sequence pairs, scaled by (B/64)^2 (about
-    ten seconds of CPU work in all)."""
+    """Oracle (PyTorch-CPU restatement of the reference path) on the host cores, same inputs and the same step (forward
+    + backward from raw head outputs to their gradients): CLIP at the benchmark batch (median of 10) and the FILIP
+    B = 256 step run IN FULL once, in 16 x 16 blocks of sequence pairs (about 25 s on 16 threads); that is `value`.
+    Beside it: CLIP at the 8-GPU global batch of 8192, and one-thread figures (CLIP in full; FILIP on the first
+    32 x 32 sequence pairs, scaled by (B/32)^2 and marked as extrapolated)."""
     from oracle import pclip_oracle as O
     t = torch.tensor(1.0)
-    ts = []
-    for _ in range(12):
-        t0 = time.perf_counter()
-        O.clip_step(cpu["e_pep"][:clip_b], cpu["e_rec"][:clip_b], t)
-        ts.append(time.perf_counter() - t0)
-    t_clip = statistics.median(ts[2:])
-    sb = 64
-    tf = []
-    for _ in range(3):
+    threads = torch.get_num_threads()
+
+    def clip_ms(B, reps, e_pep=None, e_rec=None):
+        if e_pep is None:
+            g = torch.Generator().manual_seed(0)
+            e_pep, e_rec = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            O.clip_step(e_pep[:B], e_rec[:B], t)
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts[min(2, reps - 1):]) * 1e3
+
+    def filip_s(sb):
         t0 = time.perf_counter()
         O.filip_step(cpu["hA"][:sb], cpu["hB"][:sb], cpu["mA"][:sb], cpu["mB"][:sb], t, block=16)
-        tf.append(time.perf_counter() - t0)
-    t_filip = statistics.median(tf) * (filip_b / sb) ** 2
+        return time.perf_counter() - t0
+
+    t_clip = clip_ms(clip_b, 12, cpu["e_pep"], cpu["e_rec"])
+    t_clip_8192 = clip_ms(8192, 3)
+    t_filip = filip_s(filip_b) * 1e3
+    torch.set_num_threads(1)
+    try:
+        t_clip_1 = clip_ms(clip_b, 12, cpu["e_pep"], cpu["e_rec"])
+        t_clip_8192_1 = clip_ms(8192, 1)
+        sb = 32
+        t_filip_1 = filip_s(sb) * (filip_b / sb) ** 2 * 1e3
+    finally:
+        torch.set_num_threads(threads)
     return {
-        "value": (clip_b + filip_b) / (t_clip + t_filip),
+        "value": (clip_b + filip_b) / ((t_clip + t_filip) * 1e-3),
         "unit": "pairs/s",
-        "cores": torch.get_num_threads(),
+        "cores": threads,
         "kind": "port",
-        "sample": f"CLIP B={clip_b} full step, median of 10 ({t_clip * 1e3:.3f} ms); FILIP first {sb}x{sb} sequence pairs "
-                  f"(1/{(filip_b // sb) ** 2} of the B={filip_b} step, median of 3 = {statistics.median(tf):.3f} s) scaled by "
-                  f"{(filip_b // sb) ** 2}",
-        "clip_ms": t_clip * 1e3,
-        "filip_ms_extrapolated": t_filip * 1e3,
+        "sample": f"CLIP B={clip_b} full step, median of 10 ({t_clip:.3f} ms); FILIP B={filip_b} L={L} full step, run once in "
+                  f"16x16 blocks of sequence pairs ({t_filip / 1e3:.2f} s)",
+        "extrapolated": False,
+        "clip_ms": t_clip,
+        "filip_ms": t_filip,
+        "clip_b8192_ms": t_clip_8192,
+        "one_thread": {
+            "clip_ms": t_clip_1, "clip_b8192_ms": t_clip_8192_1,
+            "filip_ms": t_filip_1, "filip_extrapolated": True,
+            "filip_sample": f"first {sb}x{sb} sequence pairs (1/{(filip_b // sb) ** 2} of the step) scaled by {(filip_b // sb) ** 2}",
+            "value": (clip_b + filip_b) / ((t_clip_1 + t_filip_1) * 1e-3),
+        },
     }
 
 
@@ -259,15 +285,19 @@ def main():
             return filip_fused.run(dv["hA"], dv["hB"], dv["mA"], dv["mB"], t, sim_events=ev, bwd_events=bev)
         return filip_sh.run(dv["hA"], dv["hB"], dv["mA"], dv["mB"], t, sim_events=ev)
 
+    allocs = {"n": 0}
+
     def bracket(fn, steps):
         """Barrier + sync, run, sync + barrier; returns seconds (max over ranks)."""
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
+        a0 = torch.cuda.memory_stats(device).get("allocation.all.allocated", 0)
         t0 = time.perf_counter()
         for i in range(steps):
             fn(i)
+        allocs["n"] = torch.cuda.memory_stats(device).get("allocation.all.allocated", 0) - a0   # by the steps themselves
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
@@ -297,6 +327,9 @@ def main():
     for i in range(args.warmup):
         step(i, ev=False)
     total = bracket(lambda i: step(i), args.steps)
+    step_allocs = allocs["n"]   # device allocations made by the timed steps
+    if multi and step_allocs != 0:
+        raise SystemExit(f"the sharded steps allocated device memory {step_allocs} times inside the timed region (expected: none)")
     sim_ms = statistics.mean(e0.elapsed_time(e1) for e0, e1 in events) if do_filip else None
     bwd_ms = statistics.mean(e0.elapsed_time(e1) for e0, e1 in bwd_events) if do_filip and filip_fused is not None else None
 
@@ -367,6 +400,10 @@ def main():
                 "ms_per_step": ms, "pairs_per_s": filip_bg / (ms * 1e-3), "scored_pairs_per_s": filip_bl * filip_bg * world / (ms * 1e-3),
                 "sim_kernel_ms": sim_ms, "sim_kernel_TFLOPs": roof["achieved"], "sim_kernel_mfma_frac": roof["frac"],
             }
+            # the whole step against the matrix peak: the algorithmic flops of the scores (the backward's routed row
+            # additions are 1.5 % of them and not counted) over the step time, so that what the backward, the
+            # preparation and the losses cost is visible beside the score kernel's own fraction
+            workloads["filip"]["step_mfma_frac"] = roof["algorithmic_flops_per_launch"] / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS
             if bwd_ms is not None:
                 # marks of mutual choices, inversions, both gathers and the prep backward (one C call)
                 workloads["filip"]["backward_ms"] = bwd_ms
@@ -393,6 +430,7 @@ def main():
             },
             "roofline": roof,
             "workloads": workloads,
+            "device_allocations_in_timed_steps": step_allocs,
         }
         if rehearse:
             out["note"] = "rehearsal of the multi-rank code on one GPU (--rehearse-dist); not a benchmark result"

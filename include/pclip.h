@@ -251,6 +251,17 @@ int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int
                         const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
                         void* stream);
 
+/* The same for a BLOCK OF COLUMNS of wider outputs: sim_A, sim_B are [Br,Bc_total], argA [Br,Bc_total,TAp],
+ * argB [Br,Bc_total,TBp], and this call fills their columns col_offset .. col_offset + Bc - 1 from the Bc
+ * sequences given (every score depends on its own sequence pair only, models.py:332-351, so any split
+ * into column blocks gives the same bits).  It lets a rank of a multi-GPU job score its own B
+ * sequences while the all-gather of the other ranks' is still in flight.  pclip_filip_sim_fwd is
+ * this call with col_offset = 0, Bc_total = Bc. */
+int pclip_filip_sim_fwd_cols(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
+                             const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,
+                             const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
+                             int col_offset, int Bc_total, void* stream);
+
 /* Step 3, backward of the scores w.r.t. the bf16 operands (autograd of models.py:332-351:
  * the max routes each gradient to its arg-max partner).  gA, gB [Br,Bc] f32 = d loss / d sim_A,
  * d loss / d sim_B.  Outputs (f32, OVERWRITTEN): dnA [Br,TA,128p] and dnB [Bc,TB,128p] hold

@@ -254,6 +254,7 @@ struct FilipArgs {
     float* simA; float* simB;
     uint16_t* argA; uint16_t* argB;
     int jchunk;  // B sequences per workgroup
+    int ldc, col0;   // the outputs are [Br, ldc(, T)] arrays of which this launch fills the columns col0 .. col0 + Bc - 1
 };
 
 // LDS: B image [TBp][256 B] swizzled | colpart float2 [4][256] | rsum float[4] | red float[4]
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void filip_sim_kernel(FilipArgs p) {
         for (int sl = 0; sl < 2; ++sl) {
             const int at = w + 4 * sl;
             if (wA[sl] == 0) {  // tile of padding only: its arg-max slots are defined (zero), nothing else to do
-                if (p.argA && at < ntA && c < 16) p.argA[((size_t)i * p.Bc + j) * p.TAp + at * 32 + acc_row(c, h)] = 0;
+                if (p.argA && at < ntA && c < 16) p.argA[((size_t)i * p.ldc + p.col0 + j) * p.TAp + at * 32 + acc_row(c, h)] = 0;
                 continue;
             }
 #pragma unroll
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void filip_sim_kernel(FilipArgs p) {
                 const int arow = acc_row(r, h);
                 const bool valid = (wA[sl] >> arow) & 1u;
                 rs += valid ? v : 0.f;
-                if (p.argA && c == r) p.argA[((size_t)i * p.Bc + j) * p.TAp + at * 32 + arow] = valid ? (uint16_t)b : (uint16_t)0;
+                if (p.argA && c == r) p.argA[((size_t)i * p.ldc + p.col0 + j) * p.TAp + at * 32 + arow] = valid ? (uint16_t)b : (uint16_t)0;
             }
         }
         rs += __shfl_xor(rs, 32);
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void filip_sim_kernel(FilipArgs p) {
                 }
                 cv = best;
             }
-            if (p.argB) p.argB[((size_t)i * p.Bc + j) * p.TBp + tid] = (uint16_t)arg;
+            if (p.argB) p.argB[((size_t)i * p.ldc + p.col0 + j) * p.TBp + tid] = (uint16_t)arg;
         }
         cv = wave_sum(cv);
         if (lane == 0) red[w] = cv;
@@ -416,8 +417,8 @@ __global__ __launch_bounds__(256, 2) void filip_sim_kernel(FilipArgs p) {
         if (tid == 0) {
             const float sa = rsum[0] + rsum[1] + rsum[2] + rsum[3];
             const float sb = red[0] + red[1] + red[2] + red[3];
-            p.simA[(size_t)i * p.Bc + j] = sa / fmaxf((float)nA, 1e-6f) * inv_t;
-            p.simB[(size_t)i * p.Bc + j] = sb / fmaxf((float)nB, 1e-6f) * inv_t;
+            p.simA[(size_t)i * p.ldc + p.col0 + j] = sa / fmaxf((float)nA, 1e-6f) * inv_t;
+            p.simB[(size_t)i * p.ldc + p.col0 + j] = sb / fmaxf((float)nB, 1e-6f) * inv_t;
         }
     }
 }
@@ -446,23 +447,26 @@ extern "C" int pclip_filip_prep_bwd(const float* h, const float* dn, int B, int 
     return filip_prep_bwd_launch(h, dn, 1, 0, FD, nullptr, B, T, d, normalise, tsign, accumulate, dh, stream);
 }
 
-extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
-                                   int Bc, int TB, const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
-                                   void* stream) {
+extern "C" int pclip_filip_sim_fwd_cols(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
+                                        int Bc, int TB, const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
+                                        int col_offset, int Bc_total, void* stream) {
     PCLIP_REQUIRE(hnA && maskwA && hnB && maskwB && t && sim_A && sim_B, "filip_sim_fwd: null pointer");
     PCLIP_REQUIRE((argA == nullptr) == (argB == nullptr), "filip_sim_fwd: pass both argA and argB or neither");
     if (int rc = filip_dims_ok("filip_sim_fwd", Br, TA, FD)) return rc;
     if (int rc = filip_dims_ok("filip_sim_fwd", Bc, TB, FD)) return rc;
+    PCLIP_REQUIRE(col_offset >= 0 && Bc_total >= 1 && col_offset + Bc <= Bc_total, "filip_sim_fwd: columns %d .. %d of %d", col_offset,
+                  col_offset + Bc - 1, Bc_total);
+    const int TAp = (TA + 31) / 32 * 32, TBp = (TB + 31) / 32 * 32;
     if (TA > PCLIP_FILIP_MAX_T || TB > PCLIP_FILIP_MAX_T)
-        return filip_sim_long_launch(hnA, maskwA, Br, (TA + 31) / 32 * 32, hnB, maskwB, Bc, (TB + 31) / 32 * 32, t, sim_A, sim_B, argA, argB,
-                                     stream);
+        return filip_sim_long_launch(hnA, maskwA, Br, TAp, hnB, maskwB, Bc, TBp, t, sim_A, sim_B, argA, argB, col_offset, Bc_total, stream);
     if (unit_norm)
-        return filip_sim_stream_launch(hnA, maskwA, Br, (TA + 31) / 32 * 32, hnB, maskwB, Bc, (TB + 31) / 32 * 32, t, sim_A, sim_B, argA, argB,
+        return filip_sim_stream_launch(hnA, maskwA, Br, TAp, hnB, maskwB, Bc, TBp, t, sim_A, sim_B, argA, argB, col_offset, Bc_total,
                                        unit_norm >= 2 ? unit_norm : 0, stream);
     FilipArgs a;
-    a.hnA = hnA; a.mwA = maskwA; a.Br = Br; a.TAp = (TA + 31) / 32 * 32;
-    a.hnB = hnB; a.mwB = maskwB; a.Bc = Bc; a.TBp = (TB + 31) / 32 * 32;
+    a.hnA = hnA; a.mwA = maskwA; a.Br = Br; a.TAp = TAp;
+    a.hnB = hnB; a.mwB = maskwB; a.Bc = Bc; a.TBp = TBp;
     a.t = t; a.simA = sim_A; a.simB = sim_B; a.argA = argA; a.argB = argB;
+    a.ldc = Bc_total; a.col0 = col_offset;
     // enough workgroups to fill 256 CUs twice over several times, but at least 8 B sequences each
     int nchunk = (2048 + Br - 1) / Br;
     if (nchunk < 1) nchunk = 1;
@@ -474,4 +478,10 @@ extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, 
     if (int rc = pclip_ensure_lds(lds_limit, (const void*)filip_sim_kernel, LDS_TOTAL, "filip_sim_kernel")) return rc;
     hipLaunchKernelGGL(filip_sim_kernel, dim3(Br * nchunk), dim3(256), LDS_TOTAL, (hipStream_t)stream, a);
     return pclip_check_launch("filip_sim_kernel");
+}
+
+extern "C" int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
+                                   int Bc, int TB, const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
+                                   void* stream) {
+    return pclip_filip_sim_fwd_cols(hnA, maskwA, Br, TA, hnB, maskwB, Bc, TB, t, unit_norm, sim_A, sim_B, argA, argB, 0, Bc, stream);
 }

@@ -20,6 +20,7 @@ struct FilipLongArgs {
     const float* t;
     float* simA; float* simB;
     uint16_t* argA; uint16_t* argB;
+    int ldc, col0;   // the outputs are [Br, ldc(, T)] arrays of which this launch fills the columns col0 .. col0 + Bc - 1
 };
 
 __global__ __launch_bounds__(256) void filip_sim_long_kernel(FilipLongArgs p) {
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void filip_sim_long_kernel(FilipLongArgs p) {
             const int arow = acc_row(r, h);
             const bool valid = (wA >> arow) & 1u;
             rs += (valid && c == 0) ? v : 0.f;
-            if (p.argA && c == r) p.argA[((size_t)i * p.Bc + j) * p.TAp + at * 32 + arow] = valid ? (uint16_t)b : (uint16_t)0;
+            if (p.argA && c == r) p.argA[((size_t)i * p.ldc + p.col0 + j) * p.TAp + at * 32 + arow] = valid ? (uint16_t)b : (uint16_t)0;
         }
     }
     rs = wave_sum(rs);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void filip_sim_long_kernel(FilipLongArgs p) {
                 if (q.x > best || (q.x == best && qa < arg)) { best = q.x; arg = qa; }
             }
             cv += best;
-            if (p.argB) p.argB[((size_t)i * p.Bc + j) * p.TBp + b] = (uint16_t)arg;
+            if (p.argB) p.argB[((size_t)i * p.ldc + p.col0 + j) * p.TBp + b] = (uint16_t)arg;
         }
     }
     cv = wave_sum(cv);
@@ -142,17 +143,19 @@ __global__ __launch_bounds__(256) void filip_sim_long_kernel(FilipLongArgs p) {
         const float inv_t = 1.f / fabsf(p.t[0]);
         const float sa = red[0] + red[1] + red[2] + red[3];
         const float sb = red[4] + red[5] + red[6] + red[7];
-        p.simA[(size_t)i * p.Bc + j] = sa / fmaxf((float)cnt[0], 1e-6f) * inv_t;
-        p.simB[(size_t)i * p.Bc + j] = sb / fmaxf((float)cnt[1], 1e-6f) * inv_t;
+        p.simA[(size_t)i * p.ldc + p.col0 + j] = sa / fmaxf((float)cnt[0], 1e-6f) * inv_t;
+        p.simB[(size_t)i * p.ldc + p.col0 + j] = sb / fmaxf((float)cnt[1], 1e-6f) * inv_t;
     }
 }
 
 int filip_sim_long_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
-                          int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, void* stream) {
+                          int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int col_offset, int ldc,
+                          void* stream) {
     FilipLongArgs a;
     a.hnA = hnA; a.mwA = maskwA; a.Br = Br; a.TAp = TAp;
     a.hnB = hnB; a.mwB = maskwB; a.Bc = Bc; a.TBp = TBp;
     a.t = t; a.simA = sim_A; a.simB = sim_B; a.argA = argA; a.argB = argB;
+    a.ldc = ldc; a.col0 = col_offset;
     const size_t lds = (size_t)4 * TBp * sizeof(float2) + 8 * sizeof(float) + 2 * sizeof(int);
     static PclipLdsLimit lds_limit;
     if (int rc = pclip_ensure_lds(lds_limit, (const void*)filip_sim_long_kernel, lds, "filip_sim_long_kernel")) return rc;

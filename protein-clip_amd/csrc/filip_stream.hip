@@ -71,6 +71,7 @@ struct FilipStreamArgs {
     float* simA; float* simB;
     uint16_t* argA; uint16_t* argB;
     int jchunk, ngroups, nchunk, cpw;
+    int ldc, col0;   // the outputs are [Br, ldc(, T)] arrays of which this launch fills the columns col0 .. col0 + Bc - 1
 #ifdef STREAM_STAMPS
     unsigned long long* dbg;
 #endif
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         for (int k = 0; k < SE / 2; ++k) g[k] = (uint32_t)__builtin_amdgcn_readlane((int)rec.y, base_lane + dq + 2 * k);
     };
 
-    uint16_t* const arg_base = p.argA ? p.argA + ((size_t)max(ISEQ(slot_isel), 0) * p.Bc + j_begin) * p.TAp : nullptr;
+    uint16_t* const arg_base = p.argA ? p.argA + ((size_t)max(ISEQ(slot_isel), 0) * p.ldc + p.col0 + j_begin) * p.TAp : nullptr;
     int KM[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) KM[r] = NEG_KEY;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
             if (head && !(fl_q & FLAG_NULL)) {
                 runB += cp_q;
                 if (fl_q & FLAG_LAST) {
-                    const size_t o = (size_t)ISEQ(e_isel) * p.Bc + j_begin + (int)(z_q & 0xff);
+                    const size_t o = (size_t)ISEQ(e_isel) * p.ldc + p.col0 + j_begin + (int)(z_q & 0xff);
                     p.simA[o] = rs_q * scA * sc0;
                     p.simB[o] = runB / nb_q * sc0;
                     runB = 0.f;
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                         barg = at * 32 + (((wd >> rr) & 1u) ? rr : __builtin_ctz(wd | 0x80000000u));   // a copy -> the row it copies
                     }
                     if (p.argB)
-                        p.argB[((size_t)ISEQ(isel) * p.Bc + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = (uint16_t)barg;
+                        p.argB[((size_t)ISEQ(isel) * p.ldc + p.col0 + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = (uint16_t)barg;
                 }
                 const float cs = half32_sum(cv, lane);
                 if (c == 0) colpart[(par3 * SE + q) * 2 + isel] = cs;
@@ -681,14 +682,15 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
 }
 
 int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
-                            int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int wgs_target,
-                            void* stream) {
+                            int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int col_offset, int ldc,
+                            int wgs_target, void* stream) {
     using C = StreamCfg;
     FilipStreamArgs a;
     a.hnA = hnA; a.mwA = maskwA; a.Br = Br; a.TAp = TAp;
     a.hnB = hnB; a.mwB = maskwB; a.Bc = Bc; a.TBp = TBp;
     a.t = t; a.simA = sim_A; a.simB = sim_B; a.argA = argA; a.argB = argB;
     a.ngroups = (Br + 1) / 2;
+    a.ldc = ldc; a.col0 = col_offset;
 #ifdef STREAM_STAMPS
     a.dbg = g_stream_dbg;
 #endif

@@ -86,11 +86,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // internal launcher of the streaming unit-norm FILIP score kernel (filip_stream.hip); wgs_target:
 // workgroups to aim at per launch (<= 0: the default)
 int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
-                            int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int wgs_target,
-                            void* stream);
+                            int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int col_offset, int ldc,
+                            int wgs_target, void* stream);
 // internal launcher of the general FILIP score kernel for long sequences (filip_long.hip)
 int filip_sim_long_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
-                          int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, void* stream);
+                          int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int col_offset, int ldc,
+                          void* stream);
 // internal launchers of the two-tower normalise kernels used by the fused CLIP step (l2norm.hip)
 int l2norm_scale_fwd_pair_launch(const float* e0, const float* e1, const float* t, float* x0, float* x1, int B, int d, float* zero_me,
                                  void* stream);

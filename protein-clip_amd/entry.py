@@ -137,9 +137,21 @@ def run(args, build_model, train_epoch, evaluate, loaders, device, rank):
     if distributed:
         dist.barrier()
     test_loss = None
-    if os.path.exists(model_save_path):
+    # whether a checkpoint exists is rank 0's to say (it wrote it; the other ranks may not even see its directory):
+    # either every rank enters the evaluation's collectives or none does
+    have_best = os.path.exists(model_save_path)
+    if distributed:
+        flag = [have_best]
+        dist.broadcast_object_list(flag, src=0)
+        have_best = bool(flag[0])
+    if have_best:
         best = build_model().to(device)
-        best.load_state_dict(torch.load(model_save_path, weights_only=True, map_location=device))
+        if distributed:   # the best state travels from rank 0 (no shared file system is assumed)
+            state = [torch.load(model_save_path, weights_only=True, map_location="cpu") if rank == 0 else None]
+            dist.broadcast_object_list(state, src=0)
+            best.load_state_dict(state[0])
+        else:
+            best.load_state_dict(torch.load(model_save_path, weights_only=True, map_location=device))
         test_loss = evaluate(best, test_loader)
         if rank == 0:
             print(f"Test Loss: {test_loss:.4f}")

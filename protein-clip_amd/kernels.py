@@ -2,7 +2,9 @@
 workspace allocation through torch, one C call each.  No arithmetic happens here."""
 from __future__ import annotations
 
+import collections
 import ctypes
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -11,23 +13,77 @@ from . import _lib
 from ._lib import check, ptr, require_gpu_tensor, stream_of
 
 F32 = torch.float32
-_ws_cache = {}
+_ws_cache = collections.OrderedDict()
+_WS_CACHE_STREAMS = 8   # scratch buffers kept: the streams used most recently (a program that makes streams for ever does not leak)
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
     """Scratch for one call: one buffer per (device, stream) that only ever grows.  Calls on one
     stream run in order, so they can share it; calls on different streams get different buffers.
-    A buffer that is outgrown may still be in use by kernels already enqueued on its stream: the
-    caching allocator is told so (``record_stream``) before the reference is dropped."""
+    A buffer that is outgrown or dropped may still be in use by kernels already enqueued on its
+    stream: the caching allocator is told so (``record_stream``) before the reference goes.
+    Nothing may rely on the CONTENTS of this buffer from one call to the next (a caller that needs
+    that — the two one-sided FILIP backward calls — brings a workspace of its own)."""
     stream = torch.cuda.current_stream(device)
     key = (device.index, stream.cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
             buf.record_stream(stream)
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        buf = _empty((max(nbytes, 1 << 20),), torch.uint8, device)
         _ws_cache[key] = buf
+    _ws_cache.move_to_end(key)
+    while len(_ws_cache) > _WS_CACHE_STREAMS:
+        _, old = _ws_cache.popitem(last=False)
+        old.record_stream(stream)   # its own stream's kernels are long enqueued; the allocator waits for this one's as well
     return buf
+
+
+class BufferArena:
+    """Replays the device allocations of a call sequence that repeats: inside ``with arena:`` every output
+    and scratch tensor the wrappers of this module would allocate is taken from the arena instead — created
+    on the first pass, handed out again, in the same order, on every later one.  A step that runs the same
+    calls on the same shapes every time (the sharded training steps) thus allocates nothing after its first
+    pass.  The tensors a pass returns are overwritten by the next pass."""
+
+    _tls = threading.local()
+
+    def __init__(self):
+        self.bufs, self.pos = [], 0
+
+    def __enter__(self):
+        self.prev = getattr(BufferArena._tls, "cur", None)
+        BufferArena._tls.cur = self
+        self.pos = 0
+        return self
+
+    def __exit__(self, *exc):
+        BufferArena._tls.cur = self.prev
+        return False
+
+    def take(self, shape, dtype, device) -> torch.Tensor:
+        shape = tuple(int(v) for v in shape)
+        if self.pos < len(self.bufs):
+            t = self.bufs[self.pos]
+            if tuple(t.shape) != shape or t.dtype != dtype or t.device != torch.device(device):
+                t = self.bufs[self.pos] = torch.empty(shape, dtype=dtype, device=device)   # the sequence changed: start over from here
+                del self.bufs[self.pos + 1:]
+        else:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self.bufs.append(t)
+        self.pos += 1
+        return t
+
+
+def _empty(shape, dtype, device) -> torch.Tensor:
+    arena = getattr(BufferArena._tls, "cur", None)
+    if arena is not None:
+        return arena.take(shape, dtype, device)
+    return torch.empty(tuple(shape), dtype=dtype, device=device)
+
+
+def _zeros(shape, dtype, device) -> torch.Tensor:
+    return _empty(shape, dtype, device).zero_()
 
 
 def _scalar(t, device, name):
@@ -135,11 +191,15 @@ def head_tail_bwd(pooled, params, keep, keep_scale: float, ln_eps: float, t, sav
 
 
 # ---- L2 normalise + scale ---------------------------------------------------------------
-def l2norm_scale_fwd(e: torch.Tensor, t) -> torch.Tensor:
+def l2norm_scale_fwd(e: torch.Tensor, t, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     require_gpu_tensor(e, F32, "e")
     B, d = e.shape
     tt = _scalar(t, e.device, "t")
-    x = torch.empty_like(e)
+    x = _empty(e.shape, F32, e.device) if out is None else out
+    if out is not None:
+        require_gpu_tensor(out, F32, "out")
+        if out.shape != e.shape:
+            raise _lib.PclipError("l2norm_scale_fwd: `out` must have the shape of `e`")
     check(_lib.load().pclip_l2norm_scale_fwd(ptr(e), ptr(tt), ptr(x), B, d, stream_of(e)), "pclip_l2norm_scale_fwd")
     return x
 
@@ -151,9 +211,9 @@ def l2norm_scale_bwd(e, t, dx, g=None, dt: Optional[torch.Tensor] = None):
     B, d = e.shape
     tt = _scalar(t, e.device, "t")
     gg = None if g is None else _scalar(g, e.device, "g")
-    de = torch.empty_like(e)
+    de = _empty(e.shape, F32, e.device)
     if dt is None:
-        dt = torch.zeros(1, dtype=F32, device=e.device)
+        dt = _zeros((1,), F32, e.device)
     check(
         _lib.load().pclip_l2norm_scale_bwd(ptr(e), ptr(tt), ptr(dx), 1, 0, ptr(gg), ptr(de), ptr(dt), B, d, stream_of(e)),
         "pclip_l2norm_scale_bwd",
@@ -174,10 +234,10 @@ def clip_fwd(X_own, Y_own, X_all, Y_all, row_offset: int = 0, logits_mode: int =
     dev = X_own.device
     nbytes = lib.pclip_clip_workspace_bytes(Br, Bg, d)
     ws = _workspace(dev, nbytes)
-    lse_row = torch.empty(Br, dtype=F32, device=dev)
-    lse_col = torch.empty(Br, dtype=F32, device=dev)
-    loss = torch.empty(1, dtype=F32, device=dev)
-    logits = torch.empty(Br, Bg, dtype=F32, device=dev) if logits_mode else None
+    lse_row = _empty((Br,), F32, dev)
+    lse_col = _empty((Br,), F32, dev)
+    loss = _empty((1,), F32, dev)
+    logits = _empty((Br, Bg), F32, dev) if logits_mode else None
     check(
         lib.pclip_clip_fwd(ptr(X_own), ptr(Y_own), ptr(X_all), ptr(Y_all), Br, Bg, d, row_offset, ptr(lse_row), ptr(lse_col),
                            ptr(loss), ptr(logits), logits_mode, ptr(ws), ws.numel(), stream_of(X_own)),
@@ -198,8 +258,8 @@ def clip_bwd(X_own, Y_own, X_all, Y_all, lse_row_all, lse_col_all, row_offset: i
     dev = X_own.device
     ws = _workspace(dev, lib.pclip_clip_workspace_bytes(Br, Bg, d))
     gg = None if g is None else _scalar(g, dev, "g")
-    dX = torch.empty_like(X_own)
-    dY = torch.empty_like(Y_own)
+    dX = _empty(X_own.shape, F32, dev)
+    dY = _empty(Y_own.shape, F32, dev)
     check(
         lib.pclip_clip_bwd(ptr(X_own), ptr(Y_own), ptr(X_all), ptr(Y_all), ptr(lse_row_all), ptr(lse_col_all), Br, Bg, d, row_offset,
                            ptr(gg), ptr(dX), ptr(dY), ptr(ws), ws.numel(), stream_of(X_own)),
@@ -285,10 +345,10 @@ def filip_loss(simA, simB, row_offset: int = 0, Bg: Optional[int] = None):
     Br, Bc = simA.shape
     Bg = Br if Bg is None else Bg
     dev = simA.device
-    lse2 = torch.empty(2, Br, dtype=F32, device=dev)
-    terms = torch.empty(2, Br, dtype=F32, device=dev)
-    loss3 = torch.empty(3, dtype=F32, device=dev)
-    gA, gB = torch.empty_like(simA), torch.empty_like(simB)
+    lse2 = _empty((2, Br), F32, dev)
+    terms = _empty((2, Br), F32, dev)
+    loss3 = _empty((3,), F32, dev)
+    gA, gB = _empty(simA.shape, F32, dev), _empty(simB.shape, F32, dev)
     check(_lib.load().pclip_filip_loss(ptr(simA), ptr(simB), Br, Bc, row_offset, Bg, ptr(lse2), ptr(loss3), ptr(gA), ptr(gB), ptr(terms),
                                        stream_of(simA)), "pclip_filip_loss")
     return loss3, gA, gB
@@ -299,10 +359,11 @@ def _tp(T: int) -> int:
     return (T + 31) // 32 * 32
 
 
-def filip_prep(h, mask, normalise: bool, tsign=None):
+def filip_prep(h, mask, normalise: bool, tsign=None, out=None):
     """h [B,T,d] f32, mask [B,T] (any integer/bool dtype) -> (hn [B,Tp,128] bf16 bits as int16,
     maskw [B,Tp/32] int32).  ``tsign``: optional device scalar; the image is negated when it
-    is negative (pass the temperature on the A side)."""
+    is negative (pass the temperature on the A side).  ``out``: optional (hn, maskw) to write into
+    (a rank's slice of the gathered buffers, so that nothing is copied in front of the all-gather)."""
     require_gpu_tensor(h, F32, "h")
     B, T, d = h.shape
     # the kernel reads one byte per token and treats any nonzero byte as valid (as .bool() does)
@@ -315,47 +376,73 @@ def filip_prep(h, mask, normalise: bool, tsign=None):
     if m8.shape != (B, T) or not m8.is_cuda:
         raise _lib.PclipError("filip_prep: mask must be a GPU tensor of shape [B,T]")
     Tp = _tp(T)
-    hn = torch.empty(B, Tp, 128, dtype=torch.int16, device=h.device)
-    mw = torch.empty(B, Tp // 32, dtype=torch.int32, device=h.device)
+    hn = _empty((B, Tp, 128), torch.int16, h.device) if out is None else out[0]
+    mw = _empty((B, Tp // 32), torch.int32, h.device) if out is None else out[1]
+    if tuple(hn.shape) != (B, Tp, 128) or tuple(mw.shape) != (B, Tp // 32) or hn.dtype != torch.int16 or mw.dtype != torch.int32 \
+            or not (hn.is_contiguous() and mw.is_contiguous()):
+        raise _lib.PclipError("filip_prep: `out` must be contiguous (int16 [B,Tp,128], int32 [B,Tp/32]) tensors")
     ts = None if tsign is None else _scalar(tsign, h.device, "tsign")
     check(_lib.load().pclip_filip_prep(ptr(h), ptr(m8), B, T, d, int(normalise), ptr(ts), ptr(hn), ptr(mw), stream_of(h)),
           "pclip_filip_prep")
     return hn, mw
 
 
-def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True, unit_norm: bool = False, stream_wgs: int = 0):
+def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True, unit_norm: bool = False, stream_wgs: int = 0,
+                  out=None, col_offset: int = 0):
     """``stream_wgs`` (tests, tuning): number of workgroups the unit-norm kernel aims at per launch
-    (0 = the library's default); the results do not depend on it."""
+    (0 = the library's default); the results do not depend on it.
+    ``out`` = (simA, simB, argA, argB) of a WIDER problem ([Br,Bc_total] and [Br,Bc_total,Tp]) together with
+    ``col_offset``: this call fills their columns col_offset .. col_offset + Bc - 1 and returns them."""
     dev = hnA.device
     Br, Bc = hnA.shape[0], hnB.shape[0]
     tt = _scalar(t, dev, "t")
-    simA = torch.empty(Br, Bc, dtype=F32, device=dev)
-    simB = torch.empty(Br, Bc, dtype=F32, device=dev)
-    argA = torch.empty(Br, Bc, _tp(TA), dtype=torch.int16, device=dev) if want_arg else None
-    argB = torch.empty(Br, Bc, _tp(TB), dtype=torch.int16, device=dev) if want_arg else None
-    check(_lib.load().pclip_filip_sim_fwd(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt),
-                                          (max(int(stream_wgs), 2) if stream_wgs else 1) if unit_norm else 0, ptr(simA),
-                                          ptr(simB), ptr(argA), ptr(argB), stream_of(hnA)), "pclip_filip_sim_fwd")
+    if out is None:
+        simA = _empty((Br, Bc), F32, dev)
+        simB = _empty((Br, Bc), F32, dev)
+        argA = _empty((Br, Bc, _tp(TA)), torch.int16, dev) if want_arg else None
+        argB = _empty((Br, Bc, _tp(TB)), torch.int16, dev) if want_arg else None
+        total = Bc
+    else:
+        simA, simB, argA, argB = out
+        total = simA.shape[1]
+        if tuple(simA.shape) != (Br, total) or tuple(simB.shape) != (Br, total) or (argA is not None and tuple(argA.shape) != (Br, total, _tp(TA))) \
+                or (argB is not None and tuple(argB.shape) != (Br, total, _tp(TB))) or not (0 <= col_offset and col_offset + Bc <= total):
+            raise _lib.PclipError("filip_sim_fwd: `out` does not match a [Br, Bc_total] problem that holds these columns")
+    check(_lib.load().pclip_filip_sim_fwd_cols(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt),
+                                               (max(int(stream_wgs), 2) if stream_wgs else 1) if unit_norm else 0, ptr(simA),
+                                               ptr(simB), ptr(argA), ptr(argB), int(col_offset), int(total), stream_of(hnA)),
+          "pclip_filip_sim_fwd_cols")
     return simA, simB, argA, argB
 
 
+def filip_bwd_workspace(Br: int, TA: int, Bc: int, TB: int, device) -> torch.Tensor:
+    """A workspace of the caller's own for ``filip_sim_bwd(..., ws=...)``: needed when a second, one-sided call
+    (``resume=True``) is to find what the first one left in it."""
+    return _empty((_lib.load().pclip_filip_bwd_workspace_bytes(Br, TA, Bc, TB),), torch.uint8, device)
+
+
 def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt: Optional[torch.Tensor] = None, sides: str = "AB",
-                  resume: bool = False):
+                  resume: bool = False, ws: Optional[torch.Tensor] = None):
     """Returns (dnA, dnB, dt).  ``sides``: "AB" (both), "A" (dnA and dt; dnB is None) or "B" (dnB only;
     dnA and dt are None) — the multi-GPU step runs "B" first and reduce-scatters dnB while "A" runs.
-    ``resume``: this is the second of two one-sided calls with the same inputs, directly after the first on
-    the same stream (the workspace still holds the first call's marks of mutual choices)."""
+    ``resume``: this is the second of two one-sided calls with the same inputs and the same ``ws``
+    (from :func:`filip_bwd_workspace`), which still holds the first call's marks of mutual choices."""
     dev = hnA.device
     Br, Bc = hnA.shape[0], hnB.shape[0]
     tt = _scalar(t, dev, "t")
     require_gpu_tensor(gA, F32, "gA")
     require_gpu_tensor(gB, F32, "gB")
-    dnA = torch.empty(Br, _tp(TA), 128, dtype=F32, device=dev) if "A" in sides else None
-    dnB = torch.empty(Bc, _tp(TB), 128, dtype=F32, device=dev) if "B" in sides else None
+    dnA = _empty((Br, _tp(TA), 128), F32, dev) if "A" in sides else None
+    dnB = _empty((Bc, _tp(TB), 128), F32, dev) if "B" in sides else None
     if dt is None:
-        dt = torch.zeros(1, dtype=F32, device=dev)
+        dt = _zeros((1,), F32, dev)
     lib = _lib.load()
-    ws = _workspace(dev, lib.pclip_filip_bwd_workspace_bytes(Br, TA, Bc, TB))
+    if resume and ws is None:
+        raise _lib.PclipError("filip_sim_bwd: resume=True needs the workspace (ws=) the first one-sided call ran on")
+    if ws is None:
+        ws = _workspace(dev, lib.pclip_filip_bwd_workspace_bytes(Br, TA, Bc, TB))
+    elif ws.numel() < lib.pclip_filip_bwd_workspace_bytes(Br, TA, Bc, TB) or ws.dtype != torch.uint8 or not ws.is_cuda:
+        raise _lib.PclipError("filip_sim_bwd: ws is too small for this problem (see filip_bwd_workspace)")
     entry = lib.pclip_filip_sim_bwd_resume if resume else lib.pclip_filip_sim_bwd
     check(entry(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), ptr(simA), ptr(simB),
                 ptr(argA), ptr(argB), ptr(gA), ptr(gB), ptr(dnA), ptr(dnB), ptr(dt), ptr(ws), ws.numel(),
@@ -373,9 +460,9 @@ def filip_bwd_fused(hnA, mwA, hnB, mwB, t, simA, simB, argA, argB, gA, gB, hA, h
         require_gpu_tensor(v, F32, n)
     (Br, TA, d), (Bc, TB, _) = hA.shape, hB.shape
     tt = _scalar(t, dev, "t")
-    dhA, dhB = torch.empty_like(hA), torch.empty_like(hB)
+    dhA, dhB = _empty(hA.shape, F32, dev), _empty(hB.shape, F32, dev)
     if dt is None:
-        dt = torch.zeros(1, dtype=F32, device=dev)
+        dt = _zeros((1,), F32, dev)
     lib = _lib.load()
     ws = _workspace(dev, lib.pclip_filip_bwd_fused_workspace_bytes(Br, TA, Bc, TB))
     check(lib.pclip_filip_bwd_fused(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), ptr(simA), ptr(simB), ptr(argA),
@@ -389,7 +476,7 @@ def filip_prep_bwd(h, dn, normalise: bool, tsign=None, out: Optional[torch.Tenso
     require_gpu_tensor(dn, F32, "dn")
     B, T, d = h.shape
     acc = out is not None
-    dh = out if acc else torch.empty_like(h)
+    dh = out if acc else _empty(h.shape, F32, h.device)
     ts = None if tsign is None else _scalar(tsign, h.device, "tsign")
     check(_lib.load().pclip_filip_prep_bwd(ptr(h), ptr(dn), B, T, d, int(normalise), ptr(ts), int(acc), ptr(dh), stream_of(h)),
           "pclip_filip_prep_bwd")

@@ -224,15 +224,26 @@ class _RowCE(torch.autograd.Function):
         return ctx.K.rowce_bwd(logits, lse, row_offset, Bg, use_dcl, g=g.reshape(1)), None, None, None, None, None
 
 
+# Off by default: scores that :func:`filip_similarity` computed under a process group carry a tag saying which rows of
+# the global matrix they are, and only tagged tensors are treated as row blocks.  Set to True to also take any
+# ``[Bl, W*Bl]`` matrix under an initialised group of W ranks for this rank's row block (a guess from the shape alone).
+INFER_ROW_SHARD_FROM_SHAPE = False
+_ROW_SHARD_TAG = "_pclip_row_shard"
+
+
 def _row_shard(logits: torch.Tensor, group):
-    """(row_offset, global_batch) of a ``[Bl, W*Bl]`` block of scores under a process group of W > 1
-    ranks: what :func:`filip_similarity` returns there (this rank's A rows against the gathered B
-    sequences), so the target of local row i is column ``rank*Bl + i`` and the mean runs over the
-    ``W*Bl`` rows of all ranks.  Any other shape is a complete matrix of its own: (0, rows)."""
-    world, rank = _world(group)
+    """(row_offset, global_batch, sharded) of a matrix of scores.  What :func:`filip_similarity` returns under a process
+    group of W > 1 ranks — this rank's ``Bl`` A rows against the gathered ``W*Bl`` B sequences — is tagged with its row
+    offset ``rank*Bl`` and the global batch: the target of local row i is column ``rank*Bl + i`` and the mean runs over
+    the rows of all ranks.  An untagged matrix is a complete one of its own: (0, rows, False)."""
+    tag = getattr(logits, _ROW_SHARD_TAG, None)
+    if tag is not None and tuple(logits.shape) == tag[2]:
+        return tag[0], tag[1], True
     Bl, Bc = logits.shape
-    if world > 1 and Bc == world * Bl:
-        return rank * Bl, Bc, True
+    if INFER_ROW_SHARD_FROM_SHAPE:
+        world, rank = _world(group)
+        if world > 1 and Bc == world * Bl:
+            return rank * Bl, Bc, True
     return 0, Bl, False
 
 
@@ -241,10 +252,10 @@ def row_ce(logits: torch.Tensor, use_dcl: bool = False, row_offset: Optional[int
     """``mean_i(-log E_ii + log sum_j E_ij)`` over the global batch; ``logits`` holds this rank's
     rows, whose targets sit at column ``i + row_offset``.
 
-    Without explicit ``row_offset`` / ``global_batch`` they follow from the shape: a ``[Bl, W*Bl]``
-    block under an initialised process group of W ranks is this rank's row block of the global
-    matrix (the loss is then summed over the ranks, every rank returns the global value and
-    back-propagates its own rows); anything else is a whole matrix with the diagonal as target."""
+    Without explicit ``row_offset`` / ``global_batch``: scores that :func:`filip_similarity` computed under a
+    process group say themselves which row block of the global matrix they are (the loss is then summed
+    over the ranks, every rank returns the global value and back-propagates its own rows); anything else
+    is a whole matrix with the diagonal as target."""
     if logits.dim() != 2:
         raise ValueError("row_ce: expected a 2-d logits tensor")
     if row_offset is None and global_batch is None:
@@ -286,12 +297,15 @@ class _FilipSim(torch.autograd.Function):
             gA, gB = gA.contiguous(), gB.contiguous()
             # every rank holds a partial gradient for every B sequence: the B side runs first, and
             # its reduce-scatter (sum, each rank gets its own sequences) beside the A side's kernels
-            _, dnB_all, _ = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB, sides="B")
+            # (the two one-sided calls share a workspace of their own: the second finds the first one's marks of
+            # mutual choices in it instead of computing them again)
+            ws = K.filip_bwd_workspace(hnA.shape[0], TA, hnB_all.shape[0], TB, hnA.device)
+            _, dnB_all, _ = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB, sides="B", ws=ws)
             dnB = torch.empty((hB.shape[0],) + tuple(dnB_all.shape[1:]), dtype=dnB_all.dtype, device=dnB_all.device)
             work = dist.reduce_scatter_tensor(dnB, dnB_all, group=group, async_op=True)
             # dt stays this rank's share, like every shared-parameter gradient: the trainer's
             # gradient all-reduce (SUM) completes it
-            dnA, _, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB, sides="A")
+            dnA, _, dt = K.filip_sim_bwd(hnA, mwA, TA, hnB_all, mwB_all, TB, t, simA, simB, argA, argB, gA, gB, sides="A", resume=True, ws=ws)
             dhA = K.filip_prep_bwd(hA, dnA, normalise, tsign=t)
             work.wait()
             dhB = K.filip_prep_bwd(hB, dnB, normalise)
@@ -323,4 +337,8 @@ def filip_similarity(hA, hB, maskA, maskB, temperature, normalise: bool = False,
             hB = torch.nn.functional.pad(hB, (0, 0, 0, extra))
             maskB = torch.nn.functional.pad(maskB, (0, extra))
     simA, simB, _, _ = _FilipSim.apply(_f32(hA), _f32(hB), maskA, maskB, _f32(t), bool(normalise), group, kernels or _hip_kernels)
+    if world > 1:   # this rank's row block of the global score matrices: row_ce reads the tag
+        _, rank = _world(group)
+        for sim in (simA, simB):
+            setattr(sim, _ROW_SHARD_TAG, (rank * hA.shape[0], world * hA.shape[0], tuple(sim.shape)))
     return simA, simB

@@ -54,8 +54,12 @@ def head_tail_bwd(pooled, params, keep, keep_scale, ln_eps, t, save, dout, dt=No
     return leaves[0].grad, [v.grad for v in leaves[1:]], out_dt
 
 
-def l2norm_scale_fwd(e, t):
-    return _l2(e, _s(t))
+def l2norm_scale_fwd(e, t, out=None):
+    res = _l2(e, _s(t))
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def l2norm_scale_bwd(e, t, dx, g=None, dt=None):
@@ -137,7 +141,11 @@ def _bf16(x):
     return x.to(torch.bfloat16).to(F32)
 
 
-def filip_prep(h, mask, normalise, tsign=None):
+def filip_bwd_workspace(Br, TA, Bc, TB, device):
+    return None
+
+
+def filip_prep(h, mask, normalise, tsign=None, out=None):
     n = h / h.norm(dim=-1, keepdim=True) if normalise else h
     if tsign is not None and float(_s(tsign)) < 0:
         n = -n
@@ -160,12 +168,19 @@ def _scores(hnA, mA, hnB, mB, t):
     return simA, simB, aA, aB
 
 
-def filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, want_arg=True, unit_norm=False, stream_wgs=0):
+def filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, want_arg=True, unit_norm=False, stream_wgs=0, out=None, col_offset=0):
     simA, simB, aA, aB = _scores(hnA, mwA, hnB, mwB, t)
+    if out is not None:   # a block of columns of a wider problem
+        cols = slice(col_offset, col_offset + hnB.shape[0])
+        out[0][:, cols] = simA
+        out[1][:, cols] = simB
+        out[2][:, cols, :aA.shape[-1]] = aA.to(torch.int16)
+        out[3][:, cols, :aB.shape[-1]] = aB.to(torch.int16)
+        return out
     return simA, simB, aA.to(torch.int16), aB.to(torch.int16)
 
 
-def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt=None, sides="AB", resume=False):
+def filip_sim_bwd(hnA, mwA, TA, hnB, mwB, TB, t, simA, simB, argA, argB, gA, gB, dt=None, sides="AB", resume=False, ws=None):
     a = hnA.detach().clone().requires_grad_(True)
     b = hnB.detach().clone().requires_grad_(True)
     with torch.enable_grad():

@@ -688,6 +688,33 @@ def test_filip_rank_shape_decomposes_over_partner_blocks(K):
     close(dt, dt_sum.cpu(), 1e-4, 1e-6)
 
 
+@pytest.mark.parametrize("TA,TB,unit", [(256, 200, True), (70, 96, False), (300, 280, True)])
+def test_filip_scores_in_column_blocks_fill_the_wide_outputs(K, TA, TB, unit):
+    """pclip_filip_sim_fwd_cols: three calls on column blocks of uneven width (the middle one first, as a rank scores
+    its own sequences before the gathered ones) leave in the wide outputs exactly what one call on all columns
+    returns — scores and arg indices, for the streaming, the generic and the long-sequence kernel."""
+    gen = torch.Generator().manual_seed(31)
+    Br, Bc, d = 10, 23, 128
+    hA, hB = O.bf16_round(torch.randn(Br, TA, d, generator=gen)), O.bf16_round(torch.randn(Bc, TB, d, generator=gen))
+    mA = O.right_padded_masks(torch.randint(1, TA + 1, (Br,), generator=gen), TA)
+    mB = O.right_padded_masks(torch.randint(1, TB + 1, (Bc,), generator=gen), TB)
+    t = dev(torch.tensor([0.8]))
+    hnA, mwA = K.filip_prep(dev(hA), dev(mA), True, tsign=t)
+    hnB, mwB = K.filip_prep(dev(hB), dev(mB), True)
+    want = K.filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, unit_norm=unit)
+    TAp, TBp = (TA + 31) // 32 * 32, (TB + 31) // 32 * 32
+    out = (torch.full((Br, Bc), float("nan"), device="cuda"), torch.full((Br, Bc), float("nan"), device="cuda"),
+           torch.full((Br, Bc, TAp), -1, dtype=torch.int16, device="cuda"), torch.full((Br, Bc, TBp), -1, dtype=torch.int16, device="cuda"))
+    for lo, hi in ((9, 16), (0, 9), (16, 23)):
+        K.filip_sim_fwd(hnA, mwA, TA, hnB[lo:hi], mwB[lo:hi], TB, t, unit_norm=unit, out=out, col_offset=lo)
+    assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
+    vA = dev(mA).bool()[:, None, :] & (dev(mB).sum(1) > 0)[None, :, None]
+    vB = dev(mB).bool()[None, :, :] & (dev(mA).sum(1) > 0)[:, None, None]
+    assert torch.equal(out[2][..., :TA][vA], want[2][..., :TA][vA]) and torch.equal(out[3][..., :TB][vB], want[3][..., :TB][vB])
+    with pytest.raises(Exception):
+        K.filip_sim_fwd(hnA, mwA, TA, hnB[:8], mwB[:8], TB, t, unit_norm=unit, out=out, col_offset=16)   # columns 16 .. 23 of 23
+
+
 @pytest.mark.parametrize("TA,TB,normalise", [(300, 270, True), (40, 333, True), (290, 64, False)])
 def test_filip_sequences_beyond_one_lds_image(K, TA, TB, normalise):
     """Chains longer than 256 tokens (the reference keeps up to 2,000 residues,
@@ -730,8 +757,13 @@ def test_filip_backward_in_two_one_sided_calls(K):
         gA, gB = dev(torch.randn(Br, Bc, generator=gen)), dev(torch.randn(Br, Bc, generator=gen))
         tt = dev(t.reshape(1))
         dnA, dnB, dt = K.filip_sim_bwd(hnA, mwA, T, hnB, mwB, T, tt, simA, simB, argA, argB, gA, gB)
-        _, dnB2, _ = K.filip_sim_bwd(hnA, mwA, T, hnB, mwB, T, tt, simA, simB, argA, argB, gA, gB, sides="B")
-        dnA2, _, dt2 = K.filip_sim_bwd(hnA, mwA, T, hnB, mwB, T, tt, simA, simB, argA, argB, gA, gB, sides="A", resume=True)
+        ws = K.filip_bwd_workspace(Br, T, Bc, T, "cuda")   # the pair's own: the second call finds the first one's marks in it
+        _, dnB2, _ = K.filip_sim_bwd(hnA, mwA, T, hnB, mwB, T, tt, simA, simB, argA, argB, gA, gB, sides="B", ws=ws)
+        # another backward in between, on the shared scratch of the stream: the pair's workspace is not touched by it
+        K.filip_sim_bwd(hnA, mwA, T, hnB, mwB, T, tt, simA, simB, argA, argB, gB, gA)
+        dnA2, _, dt2 = K.filip_sim_bwd(hnA, mwA, T, hnB, mwB, T, tt, simA, simB, argA, argB, gA, gB, sides="A", resume=True, ws=ws)
+        with pytest.raises(Exception):
+            K.filip_sim_bwd(hnA, mwA, T, hnB, mwB, T, tt, simA, simB, argA, argB, gA, gB, sides="A", resume=True)   # no workspace to resume on
         close(dnA2, dnA.cpu(), 1e-5, 2e-6)   # the order of a bucket's entries, hence of the sums, is not fixed
         close(dnB2, dnB.cpu(), 1e-5, 2e-6)
         close(dt2, dt.cpu(), 1e-5, 1e-6)

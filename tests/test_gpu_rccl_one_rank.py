@@ -89,3 +89,4 @@ def test_bench_multi_rank_path_rehearsal():
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["config"]["clip_global_batch"] == 1024 and out["value"] > 0 and "rehearsal" in out["note"]
+    assert out["device_allocations_in_timed_steps"] == 0   # the sharded steps run on buffers made once

@@ -644,10 +644,13 @@ def test_filip_benchmark_size_backward_rows_against_oracle(K):
         sA, sB, da, _, _ = _oracle_filip_grads(hA[i:i + 1], hB, mA[i:i + 1], mB, tt, True, gA[i:i + 1], gB[i:i + 1])
         close(simA[i:i + 1], sA, 3e-5, 3e-5)   # 1/t = 14 scales the 2e-6 of the unit-temperature scores
         close(simB[i:i + 1], sB, 3e-5, 3e-5)
-        mostly_close(dA[i:i + 1], da, 1e-3, 1e-7, max_bad_frac=0.03, max_rel_l2=0.02)   # measured: <= 0.03 %, 1e-4
+        # budgets = twice what tools/measure_bwd_outliers.py measured (profiles/r3_bwd_outliers.txt: <= 0.03 %, 1e-4; every
+        # outlier row is a token routed differently from the oracle at a gap below 1.5e-6, or one whose bf16 operand the
+        # device and the host rounded differently)
+        mostly_close(dA[i:i + 1], da, 1e-3, 1e-7, max_bad_frac=0.0007, max_rel_l2=2e-4)
     for j in (0, 131):   # every A sequence against B sequence j
         _, _, _, db, _ = _oracle_filip_grads(hA, hB[j:j + 1], mA, mB[j:j + 1], tt, True, gA[:, j:j + 1], gB[:, j:j + 1])
-        mostly_close(dB[j:j + 1], db, 1e-3, 1e-7, max_bad_frac=0.03, max_rel_l2=0.02)   # measured: <= 1.2 %, 8e-3
+        mostly_close(dB[j:j + 1], db, 1e-3, 1e-7, max_bad_frac=0.023, max_rel_l2=0.016)   # measured: <= 1.14 %, 7.95e-3
     for h, dh, m in ((hA, dA, mA), (hB, dB, mB)):
         assert (dh[~m.bool()] == 0).all()
         dots = (dh * h).sum(-1)[m.bool()]

@@ -139,7 +139,7 @@ def test_filip_rank_shape_256_by_2048(K):
 
     da, _ = oracle(hA[7:8], hB, mA[7:8], mB, gA[7:8], gB[7:8])
     rel = ((dA[7:8] - da).norm() / da.norm()).item()
-    assert rel < 2e-2, rel
+    assert rel < 4e-3, rel   # twice what tools/measure_bwd_outliers.py measured at this shape (profiles/r3_bwd_outliers.txt: 1.8e-3, 2.0e-3)
     _, db = oracle(hA, hB[1500:1501], mA, mB[1500:1501], gA[:, 1500:1501], gB[:, 1500:1501])
     rel = ((dB[1500:1501] - db).norm() / db.norm()).item()
-    assert rel < 2e-2, rel
+    assert rel < 4e-3, rel

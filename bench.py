@@ -194,6 +194,30 @@ def rank_shape_records(K, device):
     return out
 
 
+def long_chain_record(K, device):
+    """The FILIP scores of a batch of long chains (the reference keeps chains of up to 2,000 residues,
+    modules/data_utils_2protein.py:88,133; its FILIP entry script runs batches of 10): 16 x 16 sequences of 1,000
+    tokens and 10 x 10 of 2,000, every token valid, the call as a whole (256-token segments on the streaming
+    kernel + the joining kernel), timed with events after the main benchmark (warm clocks)."""
+    out = {}
+    t = torch.tensor([1.0], device=device)
+    for B, T in ((16, 1000), (10, 2000)):
+        g = torch.Generator().manual_seed(T)
+        hA = torch.randn(B, T, D, generator=g).to(device)
+        hB = torch.randn(B, T, D, generator=g).to(device)
+        ones = torch.ones(B, T, dtype=torch.uint8, device=device)
+        hnA, mwA = K.filip_prep(hA, ones, True, tsign=t)
+        hnB, mwB = K.filip_prep(hB, ones, True)
+        for _ in range(20):
+            K.filip_sim_fwd(hnA, mwA, T, hnB, mwB, T, t, want_arg=True, unit_norm=True)
+        ms = _median_ms(lambda: K.filip_sim_fwd(hnA, mwA, T, hnB, mwB, T, t, want_arg=True, unit_norm=True), 40)
+        fl = 2.0 * D * (B * T) ** 2
+        out[f"filip_long_b{B}_t{T}"] = {
+            "note": "scores of long chains, every token valid: segments of 256 tokens on the streaming kernel, then the join (not part of `value`)",
+            "scores_ms": ms, "algorithmic_flops": fl, "TFLOPs": fl / (ms * 1e-3) / 1e12, "mfma_frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
+    return out
+
+
 def head_record(K, device):
     """The step in front of the hot path: masked mean over tokens and the embedding head of one CLIP tower
     (Linear -> ReLU -> LayerNorm -> Dropout -> Linear -> normalise, scale), forward and backward kernels
@@ -417,6 +441,7 @@ def main():
         if not multi and not args.no_rank_shapes and args.workload == "both":
             workloads.update(rank_shape_records(K, device))
             workloads.update(head_record(K, device))
+            workloads.update(long_chain_record(K, device))
         out = {
             "metric": "protein_pairs_per_sec", "value": pairs / (total / args.steps), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": SETTLE_STEPS, "ms_per_step": total / args.steps * 1e3,

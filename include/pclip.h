@@ -245,7 +245,7 @@ int pclip_filip_prep(const float* h, const uint8_t* mask, int B, int T, int d, i
  * in inference.)
  * TA, TB <= PCLIP_FILIP_MAX_T_LONG; sequences beyond PCLIP_FILIP_MAX_T tokens (the reference keeps
  * chains of up to 2,000 residues, modules/data_utils_2protein.py:88) run on a general, untuned
- * kernel. */
+ * kernel here; pclip_filip_sim_fwd_ws below runs them at the fast kernel's rate. */
 int pclip_filip_sim_fwd(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
                         const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,
                         const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
@@ -261,6 +261,19 @@ int pclip_filip_sim_fwd_cols(const uint16_t* hnA, const uint32_t* maskwA, int Br
                              const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,
                              const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
                              int col_offset, int Bc_total, void* stream);
+
+/* The same with a workspace, which sequences beyond PCLIP_FILIP_MAX_T tokens with unit-norm operands
+ * (unit_norm != 0) use to run at the fast kernel's rate: every sequence is taken as segments of 256
+ * tokens, the streaming kernel scores all segment pairs and leaves the maximum and its partner of
+ * every token per segment pair in `ws`, and a second kernel joins the segments of each sequence pair
+ * (on equal maxima the token of the later segment).  pclip_filip_sim_fwd_workspace_bytes gives the size
+ * (0 when no workspace is used; it is bounded — the columns are worked off in blocks — at about 256 MB
+ * plus one A-side block).  With ws = NULL this is pclip_filip_sim_fwd_cols. */
+size_t pclip_filip_sim_fwd_workspace_bytes(int Br, int TA, int Bc, int TB, int unit_norm);
+int pclip_filip_sim_fwd_ws(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA,
+                           const uint16_t* hnB, const uint32_t* maskwB, int Bc, int TB,
+                           const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
+                           int col_offset, int Bc_total, void* ws, size_t ws_bytes, void* stream);
 
 /* Step 3, backward of the scores w.r.t. the bf16 operands (autograd of models.py:332-351:
  * the max routes each gradient to its arg-max partner).  gA, gB [Br,Bc] f32 = d loss / d sim_A,

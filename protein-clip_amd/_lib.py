@@ -47,6 +47,8 @@ _SIGNATURES = {
     "pclip_filip_prep": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pclip_filip_sim_fwd": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P]),
     "pclip_filip_sim_fwd_cols": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_int, c_int, _P]),
+    "pclip_filip_sim_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "pclip_filip_sim_fwd_ws": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "pclip_filip_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pclip_filip_sim_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "pclip_filip_sim_bwd_resume": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),

@@ -447,9 +447,22 @@ extern "C" int pclip_filip_prep_bwd(const float* h, const float* dn, int B, int 
     return filip_prep_bwd_launch(h, dn, 1, 0, FD, nullptr, B, T, d, normalise, tsign, accumulate, dh, stream);
 }
 
+extern "C" size_t pclip_filip_sim_fwd_workspace_bytes(int Br, int TA, int Bc, int TB, int unit_norm) {
+    if (Br < 1 || Bc < 1 || TA < 1 || TB < 1 || TA > PCLIP_FILIP_MAX_T_LONG || TB > PCLIP_FILIP_MAX_T_LONG) return 0;
+    if (!unit_norm || (TA <= PCLIP_FILIP_MAX_T && TB <= PCLIP_FILIP_MAX_T)) return 0;
+    return filip_sim_long_stream_ws_bytes(Br, (TA + 31) / 32 * 32, Bc, (TB + 31) / 32 * 32);
+}
+
 extern "C" int pclip_filip_sim_fwd_cols(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
                                         int Bc, int TB, const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
                                         int col_offset, int Bc_total, void* stream) {
+    return pclip_filip_sim_fwd_ws(hnA, maskwA, Br, TA, hnB, maskwB, Bc, TB, t, unit_norm, sim_A, sim_B, argA, argB, col_offset, Bc_total, nullptr, 0,
+                                  stream);
+}
+
+extern "C" int pclip_filip_sim_fwd_ws(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TA, const uint16_t* hnB, const uint32_t* maskwB,
+                                      int Bc, int TB, const float* t, int unit_norm, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB,
+                                      int col_offset, int Bc_total, void* ws, size_t ws_bytes, void* stream) {
     PCLIP_REQUIRE(hnA && maskwA && hnB && maskwB && t && sim_A && sim_B, "filip_sim_fwd: null pointer");
     PCLIP_REQUIRE((argA == nullptr) == (argB == nullptr), "filip_sim_fwd: pass both argA and argB or neither");
     if (int rc = filip_dims_ok("filip_sim_fwd", Br, TA, FD)) return rc;
@@ -457,8 +470,17 @@ extern "C" int pclip_filip_sim_fwd_cols(const uint16_t* hnA, const uint32_t* mas
     PCLIP_REQUIRE(col_offset >= 0 && Bc_total >= 1 && col_offset + Bc <= Bc_total, "filip_sim_fwd: columns %d .. %d of %d", col_offset,
                   col_offset + Bc - 1, Bc_total);
     const int TAp = (TA + 31) / 32 * 32, TBp = (TB + 31) / 32 * 32;
-    if (TA > PCLIP_FILIP_MAX_T || TB > PCLIP_FILIP_MAX_T)
+    if (TA > PCLIP_FILIP_MAX_T || TB > PCLIP_FILIP_MAX_T) {
+        // unit-norm operands and a workspace: 256-token segments on the streaming kernel; else the general kernel
+        if (unit_norm && ws) {
+            const size_t need = pclip_filip_sim_fwd_workspace_bytes(Br, TA, Bc, TB, unit_norm);
+            PCLIP_REQUIRE(ws_bytes >= need, "filip_sim_fwd: workspace %zu < %zu bytes", ws_bytes, need);
+            PCLIP_REQUIRE((uintptr_t)ws % 16 == 0, "filip_sim_fwd: the workspace must be 16-byte aligned");
+            return filip_sim_long_stream_launch(hnA, maskwA, Br, TAp, hnB, maskwB, Bc, TBp, t, sim_A, sim_B, argA, argB, col_offset, Bc_total, ws,
+                                                stream);
+        }
         return filip_sim_long_launch(hnA, maskwA, Br, TAp, hnB, maskwB, Bc, TBp, t, sim_A, sim_B, argA, argB, col_offset, Bc_total, stream);
+    }
     if (unit_norm)
         return filip_sim_stream_launch(hnA, maskwA, Br, TAp, hnB, maskwB, Bc, TBp, t, sim_A, sim_B, argA, argB, col_offset, Bc_total,
                                        unit_norm >= 2 ? unit_norm : 0, stream);

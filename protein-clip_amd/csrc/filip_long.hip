@@ -162,3 +162,151 @@ int filip_sim_long_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, i
     hipLaunchKernelGGL(filip_sim_long_kernel, dim3((unsigned)((size_t)Br * Bc)), dim3(256), lds, (hipStream_t)stream, a);
     return pclip_check_launch("filip_sim_long_kernel");
 }
+
+// ---- long sequences on the streaming kernel ------------------------------------------------------------------------
+// Unit-norm operands: every sequence is taken as segments of 256 tokens (its image [Tp][128] and its mask words
+// already are rows of such segments, the last one possibly short), the streaming kernel of
+// filip_stream.hip scores every (A segment, B segment) pair at its usual rate and leaves, per segment pair, the
+// maximum and its partner for every token, and a second kernel joins the segments of a sequence pair: for an A token
+// the best of its maxima over the B segments (the later segment on equal values, as the later tile wins inside the
+// streaming kernel), masked means as in modules/models.py:345-351.  The workspace holds the per-segment-pair tables;
+// the columns are worked off in blocks so that it stays within a fixed budget whatever the batch.
+#define LONG_SEG 256
+#define LONG_WS_BUDGET ((size_t)256 << 20)
+
+struct FilipJoinArgs {
+    const float* rowval; const uint16_t* rowarg; const float* colval; const uint16_t* colarg;   // [Br * segA][ldv][256]
+    const uint32_t* mwA; const uint32_t* mwB;                                                   // real mask words [Br][ntA], [Bc][ntB]
+    const float* t;
+    float* simA; float* simB; uint16_t* argA; uint16_t* argB;                                   // real outputs [Br][ldc](, Tp)
+    int Br, TAp, segA, Bc, TBp, segB;   // Bc: sequences of this column block
+    int ldv;                            // segment columns of the tables (= block sequences * segB)
+    int col0, ldc, jb0;                 // the block's first output column, output row pitch, first B sequence of the block (mask rows)
+};
+
+// The best of a token's maxima over the segments of the other side: all loads of a token in flight together
+// (at most 16 segments: 4096 tokens), the later segment on equal values.
+#define LONG_MAX_SEG 16
+__device__ __forceinline__ float join_token(const float* __restrict__ val, const uint16_t* __restrict__ arg, size_t stride, int nseg, int* out_arg) {
+    float v[LONG_MAX_SEG];
+    uint16_t g[LONG_MAX_SEG];
+#pragma unroll
+    for (int s = 0; s < LONG_MAX_SEG; ++s) {
+        v[s] = s < nseg ? val[(size_t)s * stride] : -FLT_MAX;
+        g[s] = s < nseg ? arg[(size_t)s * stride] : (uint16_t)0;
+    }
+    float best = -FLT_MAX;
+    int a = 0;
+#pragma unroll
+    for (int s = 0; s < LONG_MAX_SEG; ++s)
+        if (v[s] >= best && v[s] > -FLT_MAX) { best = v[s]; a = s * LONG_SEG + (int)g[s]; }
+    *out_arg = a;
+    return best;
+}
+
+// One workgroup of 1024 threads per sequence pair (i, j): a thread per token of either side.
+__global__ __launch_bounds__(1024) void filip_long_join_kernel(FilipJoinArgs p) {
+    __shared__ float red[32];
+    __shared__ int cnt[32];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = blockIdx.x / p.Bc, j = blockIdx.x - i * p.Bc;
+    const int ntA = p.TAp >> 5, ntB = p.TBp >> 5;
+    const uint32_t* mwA = p.mwA + (size_t)i * ntA;
+    const uint32_t* mwB = p.mwB + (size_t)(p.jb0 + j) * ntB;
+    const size_t out_pair = (size_t)i * p.ldc + p.col0 + j;
+    float sa = 0.f, sb = 0.f;
+    int na = 0, nb = 0;
+    // (the tables are read whether or not the token is valid — entries of padding tokens are inside the tables, just
+    // meaningless — so that the mask word and the table entries are one round trip, not two)
+    for (int a = tid; a < p.TAp; a += 1024) {   // rows: over the B segments (consecutive in the tables)
+        const uint32_t wd = mwA[a >> 5];
+        const int s = a / LONG_SEG, al = a - s * LONG_SEG;
+        const size_t o = ((size_t)(i * p.segA + s) * p.ldv + j * p.segB) * LONG_SEG + al;
+        int arg;
+        const float best = join_token(p.rowval + o, p.rowarg + o, LONG_SEG, p.segB, &arg);
+        if (!((wd >> (a & 31)) & 1u)) continue;
+        sa += best;
+        ++na;
+        if (p.argA) p.argA[out_pair * p.TAp + a] = (uint16_t)arg;
+    }
+    for (int b = tid; b < p.TBp; b += 1024) {   // columns: over the A segments (a table row apart)
+        const uint32_t wd = mwB[b >> 5];
+        const int s = b / LONG_SEG, bl = b - s * LONG_SEG;
+        const size_t o = ((size_t)(i * p.segA) * p.ldv + j * p.segB + s) * LONG_SEG + bl;
+        int arg;
+        const float best = join_token(p.colval + o, p.colarg + o, (size_t)p.ldv * LONG_SEG, p.segA, &arg);
+        if (!((wd >> (b & 31)) & 1u)) continue;
+        sb += best;
+        ++nb;
+        if (p.argB) p.argB[out_pair * p.TBp + b] = (uint16_t)arg;
+    }
+    sa = wave_sum(sa);
+    sb = wave_sum(sb);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { na += __shfl_xor(na, o); nb += __shfl_xor(nb, o); }
+    if (lane == 0) { red[w] = sa; red[16 + w] = sb; cnt[w] = na; cnt[16 + w] = nb; }
+    __syncthreads();
+    if (tid == 0) {
+        const float inv_t = 1.f / fabsf(p.t[0]);
+        float ta = 0.f, tb = 0.f;
+        int ca = 0, cb = 0;
+        for (int k = 0; k < 16; ++k) { ta += red[k]; tb += red[16 + k]; ca += cnt[k]; cb += cnt[16 + k]; }
+        p.simA[out_pair] = ta / fmaxf((float)ca, 1e-6f) * inv_t;
+        p.simB[out_pair] = tb / fmaxf((float)cb, 1e-6f) * inv_t;
+    }
+}
+
+struct FilipLongPlan { int segA, segB, blk; size_t rowval, colval, rowarg, colarg, sims, total; };
+
+static FilipLongPlan filip_long_plan(int Br, int TAp, int Bc, int TBp) {
+    FilipLongPlan P;
+    P.segA = (TAp + LONG_SEG - 1) / LONG_SEG;
+    P.segB = (TBp + LONG_SEG - 1) / LONG_SEG;
+    const size_t brv = (size_t)Br * P.segA;
+    // per B sequence of a column block: two tables of (f32 + u16) per token of every (A segment, B segment) pair, and two dummy scores
+    const size_t per_seq = brv * P.segB * (LONG_SEG * 12 + 8);
+    size_t blk = LONG_WS_BUDGET / per_seq;
+    if (blk < 1) blk = 1;
+    if (blk > (size_t)Bc) blk = (size_t)Bc;
+    P.blk = (int)blk;
+    const size_t pairs = brv * blk * P.segB;
+    size_t off = 0;
+    P.rowval = off; off += pclip_align_up(pairs * LONG_SEG * 4, 256);
+    P.colval = off; off += pclip_align_up(pairs * LONG_SEG * 4, 256);
+    P.rowarg = off; off += pclip_align_up(pairs * LONG_SEG * 2, 256);
+    P.colarg = off; off += pclip_align_up(pairs * LONG_SEG * 2, 256);
+    P.sims = off; off += pclip_align_up(pairs * 2 * 4, 256);
+    P.total = off;
+    return P;
+}
+
+size_t filip_sim_long_stream_ws_bytes(int Br, int TAp, int Bc, int TBp) { return filip_long_plan(Br, TAp, Bc, TBp).total; }
+
+int filip_sim_long_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
+                                 int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int col_offset, int ldc,
+                                 void* ws, void* stream) {
+    const FilipLongPlan P = filip_long_plan(Br, TAp, Bc, TBp);
+    char* w = (char*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    const int brv = Br * P.segA;
+    for (int jb0 = 0; jb0 < Bc; jb0 += P.blk) {
+        const int nb = Bc - jb0 < P.blk ? Bc - jb0 : P.blk;
+        const int ldv = nb * P.segB;
+        float* sims = (float*)(w + P.sims);
+        // the block's B segments: images from sequence jb0 on, mask rows from segment jb0 * segB on
+        if (int rc = filip_sim_stream_launch_seg(hnA, maskwA, brv, LONG_SEG, P.segA, TAp, hnB + (size_t)jb0 * TBp * FD, maskwB + (size_t)jb0 * (TBp >> 5),
+                                                 ldv, LONG_SEG, P.segB, TBp >> 5, t, sims, sims + (size_t)brv * ldv, (uint16_t*)(w + P.rowarg),
+                                                 (uint16_t*)(w + P.colarg), (float*)(w + P.rowval), (float*)(w + P.colval), 0, ldv, 0, stream))
+            return rc;
+        FilipJoinArgs a;
+        a.rowval = (const float*)(w + P.rowval); a.rowarg = (const uint16_t*)(w + P.rowarg);
+        a.colval = (const float*)(w + P.colval); a.colarg = (const uint16_t*)(w + P.colarg);
+        a.mwA = maskwA; a.mwB = maskwB; a.t = t;
+        a.simA = sim_A; a.simB = sim_B; a.argA = argA; a.argB = argB;
+        a.Br = Br; a.TAp = TAp; a.segA = P.segA; a.Bc = nb; a.TBp = TBp; a.segB = P.segB;
+        a.ldv = ldv; a.col0 = col_offset + jb0; a.ldc = ldc; a.jb0 = jb0;
+        hipLaunchKernelGGL(filip_long_join_kernel, dim3((unsigned)((size_t)Br * nb)), dim3(1024), 0, st, a);
+        if (int rc = pclip_check_launch("filip_long_join_kernel")) return rc;
+    }
+    return PCLIP_OK;
+}

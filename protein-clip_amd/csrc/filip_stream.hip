@@ -72,6 +72,13 @@ struct FilipStreamArgs {
     uint16_t* argA; uint16_t* argB;
     int jchunk, ngroups, nchunk, cpw;
     int ldc, col0;   // the outputs are [Br, ldc(, T)] arrays of which this launch fills the columns col0 .. col0 + Bc - 1
+    // Sequences longer than 256 tokens arrive cut into SEGMENTS of 256 (filip_long.hip): "sequence" g of this kernel is then
+    // segment g % seg of sequence g / seg, whose image starts 256 (g % seg) token rows into that sequence's `rows` rows
+    // (B side: 8 (g % seg) tiles into its `tiles` tiles), and its mask words are eight of the sequence's.  seg = 1: whole sequences.
+    int segA, rowsA, segB, tilesB;
+    int plain;   // segments: block b is (pair b % ngroups, chunk b / ngroups), no ranking of the pairs by cost (with few, similar
+                 // pairs the ranked dealing leaves some shader engines twice the work of others)
+    float* rowval; float* colval;   // optional [Br, ldc, 256]: the maximum behind every argA / argB entry (unscaled; -FLT_MAX: none)
 #ifdef STREAM_STAMPS
     unsigned long long* dbg;
 #endif
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     int chunk = blockIdx.x / p.ngroups;
     int srank = -1;
 #ifndef ABL_NOPAIR
-    if (p.Br <= NW * 64) {
+    if (p.Br <= NW * 64 && !p.plain) {
         // an engine's list: chunks in blocks of `cpw` (what its 8 CUs run at the same time stays within few chunks of B,
         // which its XCD's L2 then holds), inside a block the pairs heaviest first
         const int r = blockIdx.x & 31, k = blockIdx.x >> 5;
@@ -245,7 +252,8 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         int cls = -1;
         if (tid < p.Br) {
             int nt = 0;
-            for (int k = 0; k < ntA; ++k) nt += p.mwA[(size_t)tid * ntA + k] != 0u;
+            const int ntr = p.rowsA >> 5, s8 = (tid % p.segA) * 8;   // (segment tid % segA of sequence tid / segA)
+            for (int k = 0; k < ntA && s8 + k < ntr; ++k) nt += p.mwA[(size_t)(tid / p.segA) * ntr + s8 + k] != 0u;
             cls = nt & 3;
             ntmem[tid] = (uint8_t)nt;
         }
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
             pairmem[2 * pid + pos] = (uint16_t)tid;
         }
         __syncthreads();
-        {   // rank the pairs by cost = tile rounds of their workgroups (ceil(tiles / 4)), heaviest first, ties in index order
+        if (!p.plain) {   // rank the pairs by cost = tile rounds of their workgroups (ceil(tiles / 4)), heaviest first, ties in index order
             int cost = -1;
             if (tid < p.ngroups) {
                 const int m0 = pairmem[2 * tid], m1 = pairmem[2 * tid + 1];
@@ -316,7 +324,13 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     // ---- set-up: A mask words, column-key array, the B tile stream ---------------------------
     if (tid < 16) {
         const int isel = tid >> 3, at = tid & 7;
-        mwa_l[tid] = (ISEQ(isel) >= 0 && at < ntA) ? p.mwA[(size_t)ISEQ(isel) * ntA + at] : 0u;
+        uint32_t wd = 0u;
+        if (ISEQ(isel) >= 0 && at < ntA) {
+            // segment ISEQ % segA of sequence ISEQ / segA: its tiles 8 (ISEQ % segA) + at, none behind the sequence's last
+            const int tile = (ISEQ(isel) % p.segA) * 8 + at, nt = p.rowsA >> 5;
+            if (tile < nt) wd = p.mwA[(size_t)(ISEQ(isel) / p.segA) * nt + tile];
+        }
+        mwa_l[tid] = wd;
     }
     for (int k = tid; k < 2 * SE * 2 * 32; k += NW * 64) col64[k] = NEG_KEY64;
     if (w == 1) {  // one wave lays out the stream: lane = local B sequence
@@ -325,10 +339,16 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         int nvt = 0, ntok = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            wd[k] = (jl < nj && k < ntB) ? p.mwB[(size_t)(j_begin + jl) * ntB + k] : 0u;
+            wd[k] = 0u;
+            if (jl < nj && k < ntB) {
+                const int tile = ((j_begin + jl) % p.segB) * 8 + k;
+                if (tile < p.tilesB) wd[k] = p.mwB[(size_t)((j_begin + jl) / p.segB) * p.tilesB + tile];
+            }
             nvt += wd[k] != 0;
             ntok += __popc(wd[k]);
         }
+        const int jg = j_begin + jl;   // first tile of the sequence's image among all 32-token tiles of hnB
+        const uint32_t tile0 = p.segB == 1 ? (uint32_t)(jg * p.tilesB) : (uint32_t)((jg / p.segB) * p.tilesB + (jg % p.segB) * 8);
         const int mine = jl < nj ? max(nvt, 1) : 0;  // an empty sequence still gets one (empty) entry
         int incl = mine;
 #pragma unroll
@@ -347,7 +367,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 for (int k = 0; k < 8; ++k)
                     if (wd[k]) {
                         ++seen;
-                        meta[pos++] = make_uint4(wd[k], (uint32_t)((j_begin + jl) * ntB + k), (uint32_t)(jl | (k << 8)) | ((seen == nvt ? FLAG_LAST : 0u) << 16),
+                        meta[pos++] = make_uint4(wd[k], tile0 + (uint32_t)k, (uint32_t)(jl | (k << 8)) | ((seen == nvt ? FLAG_LAST : 0u) << 16),
                                                  seen == nvt ? FLAG_LAST : 0u);
                     }
             }
@@ -387,7 +407,9 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         // exactly, so no column maximum changes and no row of the tile has to be masked out of the column side; a
         // column winner that is such a copy is mapped back to the row it copies where the columns are finished.
         const int arow = ((wA >> c) & 1u) ? c : __builtin_ctz(wA | 0x80000000u);
-        const uint16_t* src = p.hnA + ((size_t)max(ISEQ(slot_isel), 0) * p.TAp + slot_at * 32 + arow) * FD + 8 * h;
+        const int ig = max(ISEQ(slot_isel), 0);
+        const size_t row0 = p.segA == 1 ? (size_t)ig * p.rowsA : (size_t)(ig / p.segA) * p.rowsA + (size_t)(ig % p.segA) * 256;
+        const uint16_t* src = p.hnA + (row0 + slot_at * 32 + arow) * FD + 8 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) afr[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
     }
@@ -431,6 +453,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     };
 
     uint16_t* const arg_base = p.argA ? p.argA + ((size_t)max(ISEQ(slot_isel), 0) * p.ldc + p.col0 + j_begin) * p.TAp : nullptr;
+    float* const rowval_base = p.rowval ? p.rowval + ((size_t)max(ISEQ(slot_isel), 0) * p.ldc + p.col0 + j_begin) * p.TAp : nullptr;
     int KM[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) KM[r] = NEG_KEY;
@@ -613,6 +636,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 if (h == 0 && p.argA)   // scalar base of this wave's A sequence and B chunk, 32-bit lane offset
                     arg_base[(uint32_t)((int)(mz & 0xff) * p.TAp + slot_at * 32 + c)] =
                         (none || !valid) ? (uint16_t)0 : (uint16_t)(((m >> 4) & 7) * 32 + cc);
+                if (h == 0 && rowval_base) rowval_base[(uint32_t)((int)(mz & 0xff) * p.TAp + slot_at * 32 + c)] = val;
                 STAMP(4);
             }
         }
@@ -652,6 +676,8 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                     }
                     if (p.argB)
                         p.argB[((size_t)ISEQ(isel) * p.ldc + p.col0 + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = (uint16_t)barg;
+                    if (p.colval)
+                        p.colval[((size_t)ISEQ(isel) * p.ldc + p.col0 + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = cv;
                 }
                 const float cs = half32_sum(cv, lane);
                 if (c == 0) colpart[(par3 * SE + q) * 2 + isel] = cs;
@@ -684,6 +710,14 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
 int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
                             int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int col_offset, int ldc,
                             int wgs_target, void* stream) {
+    return filip_sim_stream_launch_seg(hnA, maskwA, Br, TAp, 1, TAp, hnB, maskwB, Bc, TBp, 1, TBp >> 5, t, sim_A, sim_B, argA, argB, nullptr, nullptr,
+                                       col_offset, ldc, wgs_target, stream);
+}
+
+int filip_sim_stream_launch_seg(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, int segA, int rowsA, const uint16_t* hnB,
+                                const uint32_t* maskwB, int Bc, int TBp, int segB, int tilesB, const float* t, float* sim_A, float* sim_B,
+                                uint16_t* argA, uint16_t* argB, float* rowval, float* colval, int col_offset, int ldc, int wgs_target,
+                                void* stream) {
     using C = StreamCfg;
     FilipStreamArgs a;
     a.hnA = hnA; a.mwA = maskwA; a.Br = Br; a.TAp = TAp;
@@ -691,6 +725,8 @@ int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br,
     a.t = t; a.simA = sim_A; a.simB = sim_B; a.argA = argA; a.argB = argB;
     a.ngroups = (Br + 1) / 2;
     a.ldc = ldc; a.col0 = col_offset;
+    a.segA = segA; a.rowsA = rowsA; a.segB = segB; a.tilesB = tilesB; a.rowval = rowval; a.colval = colval;
+    a.plain = segA > 1 || segB > 1;
 #ifdef STREAM_STAMPS
     a.dbg = g_stream_dbg;
 #endif
@@ -702,6 +738,19 @@ int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br,
     int jchunk = (Bc + nchunk - 1) / nchunk;
     if (jchunk < 8) jchunk = Bc < 8 ? Bc : 8;
     if (jchunk > SMAXJ) jchunk = SMAXJ;
+    if (segA > 1 || segB > 1) {
+        // Segments of long sequences: few, nearly full "sequences" (8 tiles each).  The workgroups of a launch run in
+        // rounds of one per compute unit, so the chunk length is the one with the shortest estimated time
+        // rounds x (tile steps of a chunk + a workgroup's set-up, about nine tile steps), fewer workgroups on a tie.
+        const long cus = 256;
+        long best = -1;
+        for (int jc = 1; jc <= SMAXJ && jc <= Bc; ++jc) {
+            const long nwg = (long)a.ngroups * ((Bc + jc - 1) / jc);
+            const long est = ((nwg + cus - 1) / cus) * (8L * jc + 9);
+            if (best < 0 || est < best) { best = est; jchunk = jc; }   // ascending: the longest chunk wins a tie last -> use <=
+            else if (est == best) jchunk = jc;
+        }
+    }
     nchunk = (Bc + jchunk - 1) / jchunk;
     a.jchunk = jchunk;
     a.nchunk = nchunk;
@@ -711,7 +760,7 @@ int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br,
     unsigned nblocks = (unsigned)(a.ngroups * nchunk);
     a.cpw = 1;
 #ifndef ABL_NOPAIR
-    if (Br <= C::NW * 64) {
+    if (Br <= C::NW * 64 && !a.plain) {
         const int rows = (a.ngroups + 31) / 32;
         a.cpw = rows >= 8 ? 1 : 8 / rows;                                  // chunks that an engine's 8 CUs work on together
         const int nblk = (nchunk + a.cpw - 1) / a.cpw;                     // chunk blocks (the last one may be short)

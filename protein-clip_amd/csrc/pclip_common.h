@@ -88,6 +88,11 @@ __device__ __forceinline__ float wave_max(float v) {
 int filip_sim_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
                             int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int col_offset, int ldc,
                             int wgs_target, void* stream);
+// the same with the sequences given as segments of 256 tokens (see FilipStreamArgs) and the per-token maxima as extra outputs
+int filip_sim_stream_launch_seg(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, int segA, int rowsA, const uint16_t* hnB,
+                                const uint32_t* maskwB, int Bc, int TBp, int segB, int tilesB, const float* t, float* sim_A, float* sim_B,
+                                uint16_t* argA, uint16_t* argB, float* rowval, float* colval, int col_offset, int ldc, int wgs_target,
+                                void* stream);
 // internal launcher of the general FILIP score kernel for long sequences (filip_long.hip)
 int filip_sim_long_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
                           int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int col_offset, int ldc,
@@ -100,6 +105,12 @@ int l2norm_scale_bwd_pair_launch(const float* e0, const float* e1, const float* 
 // internal launcher of the prep backward over a sum of gradient slabs (filip.hip)
 int filip_prep_bwd_launch(const float* h, const float* dn, int nslab, size_t slab_stride, size_t row_stride, const uint32_t* mw, int B, int T, int d,
                           int normalise, const float* tsign, int accumulate, float* dh, void* stream);
+
+// long unit-norm sequences as 256-token segments on the streaming kernel, joined by a second kernel (filip_long.hip)
+size_t filip_sim_long_stream_ws_bytes(int Br, int TAp, int Bc, int TBp);
+int filip_sim_long_stream_launch(const uint16_t* hnA, const uint32_t* maskwA, int Br, int TAp, const uint16_t* hnB, const uint32_t* maskwB, int Bc,
+                                 int TBp, const float* t, float* sim_A, float* sim_B, uint16_t* argA, uint16_t* argB, int col_offset, int ldc,
+                                 void* ws, void* stream);
 
 // ---- the one-launch CLIP step for B <= 512 (clip_step.hip) ----
 bool clip_step_fused_ok(int B, int d);

@@ -408,10 +408,13 @@ def filip_sim_fwd(hnA, mwA, TA: int, hnB, mwB, TB: int, t, want_arg: bool = True
         if tuple(simA.shape) != (Br, total) or tuple(simB.shape) != (Br, total) or (argA is not None and tuple(argA.shape) != (Br, total, _tp(TA))) \
                 or (argB is not None and tuple(argB.shape) != (Br, total, _tp(TB))) or not (0 <= col_offset and col_offset + Bc <= total):
             raise _lib.PclipError("filip_sim_fwd: `out` does not match a [Br, Bc_total] problem that holds these columns")
-    check(_lib.load().pclip_filip_sim_fwd_cols(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt),
-                                               (max(int(stream_wgs), 2) if stream_wgs else 1) if unit_norm else 0, ptr(simA),
-                                               ptr(simB), ptr(argA), ptr(argB), int(col_offset), int(total), stream_of(hnA)),
-          "pclip_filip_sim_fwd_cols")
+    lib = _lib.load()
+    un = (max(int(stream_wgs), 2) if stream_wgs else 1) if unit_norm else 0
+    nws = lib.pclip_filip_sim_fwd_workspace_bytes(Br, TA, Bc, TB, un)   # sequences beyond 256 tokens, unit norm: segments on the fast kernel
+    ws = _workspace(dev, nws) if nws else None
+    check(lib.pclip_filip_sim_fwd_ws(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(tt), un, ptr(simA), ptr(simB), ptr(argA), ptr(argB),
+                                     int(col_offset), int(total), ptr(ws), ws.numel() if ws is not None else 0, stream_of(hnA)),
+          "pclip_filip_sim_fwd_ws")
     return simA, simB, argA, argB
 
 

@@ -718,11 +718,64 @@ def test_filip_scores_in_column_blocks_fill_the_wide_outputs(K, TA, TB, unit):
         K.filip_sim_fwd(hnA, mwA, TA, hnB[:8], mwB[:8], TB, t, unit_norm=unit, out=out, col_offset=16)   # columns 16 .. 23 of 23
 
 
-@pytest.mark.parametrize("TA,TB,normalise", [(300, 270, True), (40, 333, True), (290, 64, False)])
+def test_filip_long_segments_agree_with_the_general_kernel(K):
+    """Sequences beyond 256 tokens, unit norm: the segmented run on the streaming kernel (pclip_filip_sim_fwd_ws with a
+    workspace) against the general long-sequence kernel (the same entry without one) — scores to 2e-6, and every arg
+    index of either run attains the row / column maximum of the float64 similarities to 2e-6.  Ragged lengths, one
+    sequence shorter than a segment, one empty, a column block of a wider output."""
+    from protein_clip_amd import _lib
+    from protein_clip_amd._lib import ptr, stream_of
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(77)
+    Br, Bc, TA, TB, d = 5, 6, 1000, 700, 128
+    hA, hB = O.bf16_round(torch.randn(Br, TA, d, generator=gen)), O.bf16_round(torch.randn(Bc, TB, d, generator=gen))
+    lA = torch.tensor([1000, 513, 100, 777, 256])
+    lB = torch.tensor([700, 0, 257, 31, 512, 699])
+    mA, mB = O.right_padded_masks(lA, TA), O.right_padded_masks(lB, TB)
+    t = dev(torch.tensor([1.0]))
+    hnA, mwA = K.filip_prep(dev(hA), dev(mA), True, tsign=t)
+    hnB, mwB = K.filip_prep(dev(hB), dev(mB), True)
+    TAp, TBp, wide = 1024, 704, 9
+    nws = lib.pclip_filip_sim_fwd_workspace_bytes(Br, TA, Bc, TB, 1)
+    assert nws > 0 and lib.pclip_filip_sim_fwd_workspace_bytes(Br, 200, Bc, 256, 1) == 0
+    res = []
+    for ws in (torch.empty(nws, dtype=torch.uint8, device="cuda"), None):
+        sA, sB = torch.full((Br, wide), float("nan"), device="cuda"), torch.full((Br, wide), float("nan"), device="cuda")
+        aA = torch.full((Br, wide, TAp), -1, dtype=torch.int16, device="cuda")
+        aB = torch.full((Br, wide, TBp), -1, dtype=torch.int16, device="cuda")
+        rc = lib.pclip_filip_sim_fwd_ws(ptr(hnA), ptr(mwA), Br, TA, ptr(hnB), ptr(mwB), Bc, TB, ptr(t), 1, ptr(sA), ptr(sB), ptr(aA), ptr(aB), 2, wide,
+                                        ptr(ws), nws if ws is not None else 0, stream_of(hnA))
+        assert rc == 0, lib.pclip_last_error()
+        torch.cuda.synchronize()
+        assert torch.isnan(sA[:, :2]).all() and torch.isnan(sA[:, 8:]).all()   # only the block's columns are written
+        res.append((sA[:, 2:8], sB[:, 2:8], aA[:, 2:8], aB[:, 2:8]))
+    nA = hnA.view(torch.bfloat16).double()[:, :TA]
+    nB = hnB.view(torch.bfloat16).double()[:, :TB]
+    S = torch.einsum("iad,jbd->ijab", nA, nB)
+    ok = dev(mA).bool()[:, None, :, None] & dev(mB).bool()[None, :, None, :]
+    S = S.masked_fill(~ok, -1e30)
+    for sA, sB, aA, aB in res:
+        rows = dev(mA).bool()[:, None, :] & (dev(lB) > 0)[None, :, None]
+        cols = dev(mB).bool()[None, :, :] & (dev(lA) > 0)[:, None, None]
+        gotr = torch.gather(S, 3, aA[..., :TA].long().clamp(0, TB - 1)[..., None])[..., 0]
+        gotc = torch.gather(S, 2, aB[..., :TB].long().clamp(0, TA - 1)[:, :, None, :])[:, :, 0, :]
+        assert ((S.amax(3) - gotr)[rows].abs() <= 2e-6).all() and ((S.amax(2) - gotc)[cols].abs() <= 2e-6).all()
+        wantA = torch.where(rows, S.amax(3), torch.zeros((), dtype=torch.float64, device="cuda")).sum(-1) / dev(lA).clamp(min=1)[:, None]
+        wantB = torch.where(cols, S.amax(2), torch.zeros((), dtype=torch.float64, device="cuda")).sum(-1) / dev(lB).clamp(min=1)[None, :]
+        keep = dev(lB) > 0   # an empty B sequence: minus infinity on the row side
+        close(sA[:, keep], wantA[:, keep].float().cpu(), 2e-6, 2e-6)
+        close(sB[:, keep], wantB[:, keep].float().cpu(), 2e-6, 2e-6)
+        assert torch.isinf(sA[:, ~keep]).all() and (sB[:, ~keep] == 0).all()
+    close(res[0][0][:, keep], res[1][0][:, keep].cpu(), 2e-6, 2e-6)
+    close(res[0][1], res[1][1].cpu(), 2e-6, 2e-6)
+
+
+@pytest.mark.parametrize("TA,TB,normalise", [(300, 270, True), (40, 333, True), (290, 64, False), (1000, 1000, True), (2000, 600, True)])
 def test_filip_sequences_beyond_one_lds_image(K, TA, TB, normalise):
     """Chains longer than 256 tokens (the reference keeps up to 2,000 residues,
-    data_utils_2protein.py:88) run on the general kernel: scores, arg-max routing and the
-    backward against the oracle, ragged masks, one empty middle stretch."""
+    data_utils_2protein.py:88): scores, arg-max routing and the backward against the oracle, ragged masks,
+    one empty middle stretch.  Normalised operands run as 256-token segments on the streaming kernel,
+    others on the general kernel."""
     gen = torch.Generator().manual_seed(TA * 1000 + TB)
     B, d = 3, 128
     hA, hB = torch.randn(B, TA, d, generator=gen), torch.randn(B, TB, d, generator=gen)

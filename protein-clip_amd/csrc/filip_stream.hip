@@ -551,7 +551,15 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 {
                     const unsigned char* base = smem + C::S_RING + (ring0 + q) * TILE_BYTES + lane * 16;
 #pragma unroll
+#ifdef ABL_NOFRAG   // timing experiments only: no fragment reads (wrong results)
+                    for (int s = 0; s < 8; ++s) { bfr[s] = afr[(s + 1) & 7]; asm volatile("" : "+v"(bfr[s])); }
+                    asm volatile("" ::"v"(base));
+#elif defined(ABL_HALFFRAG)   // timing experiments only: half the fragment reads
+                    for (int s = 0; s < 4; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(base + 1024 * s);
+                    for (int s = 4; s < 8; ++s) { bfr[s] = bfr[s - 4]; asm volatile("" : "+v"(bfr[s])); }
+#else
                     for (int s = 0; s < 8; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(base + 1024 * s);
+#endif
                 }
                 const f32x16 four = {4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f};
                 f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], four, 0, 0, 0);
@@ -582,7 +590,11 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 else row_fold<false>(key, KM);
                 fresh = false;
                 const int cb = col_max(key);
+#ifndef ABL_NOATOMIC
                 atomicMax(&col64[((par2 * SE + q) * 2 + slot_isel) * 32 + c], ((long long)cb << 32) | (long long)((slot_at << 1) | h));
+#else
+                asm volatile("" ::"v"(cb));
+#endif
 #endif
                 STAMP(3);
             }

@@ -91,7 +91,7 @@ struct FilipStreamArgs {
 // tiles (longer epochs amortise the per-epoch barrier, DMA issue and duties: 4-5 % faster than
 // two), two epochs in the ring.
 struct StreamCfg {
-    static constexpr int NW = 16;
+    static constexpr int NW = 8;
 #ifndef STREAM_SE
 #define STREAM_SE 4
 #define STREAM_SNE 2
@@ -102,10 +102,10 @@ struct StreamCfg {
     static constexpr int SMAXT = SMAXJ * 8 + SE;
     static constexpr int S_RING = 0;
     static constexpr int S_TR = SR * TILE_BYTES;                 // int   [NW][32][36]
-    static constexpr int S_COL = S_TR + NW * 32 * 36 * 4;        // i64   [2 par][SE][2 isel][32 c]
-    static constexpr int S_ROWP = S_COL + 2 * SE * 2 * 32 * 8;   // float [3 par][SE][16 A tiles]
-    static constexpr int S_COLP = S_ROWP + 3 * SE * 16 * 4;      // float [3 par][SE][2 isel]
-    static constexpr int S_MWA = S_COLP + 3 * SE * 2 * 4;        // u32   [2][8]
+    static constexpr int S_COL = S_TR + NW * 32 * 36 * 4;        // i64   [3 par][SE][2 isel][32 c]
+    static constexpr int S_ROWP = S_COL + 3 * SE * 2 * 32 * 8;   // float [4 par][SE][16 A tiles]
+    static constexpr int S_COLP = S_ROWP + 4 * SE * 16 * 4;      // float [4 par][SE][2 isel]
+    static constexpr int S_MWA = S_COLP + 4 * SE * 2 * 4;        // u32   [2][8]
     static constexpr int S_CNT = S_MWA + 64;                     // int   [4]: stream length
     static constexpr int S_SCL = S_CNT + 16;                     // float [4]: 1/|t|, 1/nA[0], 1/nA[1]
     static constexpr int S_NB = S_SCL + 16;                      // int   [SMAXJ] valid tokens of each B sequence
@@ -191,7 +191,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N < 0, "add the wait count");
 }
 
-__global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void filip_sim_stream_kernel(FilipStreamArgs p) {
     using C = StreamCfg;
     constexpr int NW = C::NW, SE = C::SE, SNE = C::SNE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         }
         mwa_l[tid] = wd;
     }
-    for (int k = tid; k < 2 * SE * 2 * 32; k += NW * 64) col64[k] = NEG_KEY64;
+    for (int k = tid; k < 3 * SE * 2 * 32; k += NW * 64) col64[k] = NEG_KEY64;
     if (w == 1) {  // one wave lays out the stream: lane = local B sequence
         const int jl = lane;
         uint32_t wd[8];
@@ -380,9 +380,10 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     __syncthreads();
 #define MWA(isel, at) ((uint32_t)__builtin_amdgcn_readfirstlane((int)mwa_l[(isel) * 8 + (at)]))
 
-    // ---- deal the valid A tiles of the two sequences to the waves: item k -> wave k ----------
-    int slot_isel = 0, slot_at = 0, n_items = 0;
-    uint32_t wA = 0u;
+    // ---- deal the valid A tiles of the two sequences to the waves: item k -> wave k % NW, slot k / NW ------
+    // (wave w and w + 4 share a SIMD: the SIMDs carry ceil(n / 4) tiles each, waves 4-7 never more than 0-3)
+    int s_isel0 = 0, s_at0 = 0, s_isel1 = 0, s_at1 = 0, n_items = 0;
+    uint32_t wA0 = 0u, wA1 = 0u;
     {
         int item = 0, nA0 = 0, nA1 = 0;
         for (int isel = 0; isel < 2; ++isel)
@@ -390,7 +391,8 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
                 const uint32_t wd = MWA(isel, at);
                 if (isel == 0) nA0 += __popc(wd); else nA1 += __popc(wd);
                 if (wd) {
-                    if (item == w) { slot_isel = isel; slot_at = at; wA = wd; }
+                    if (item == w) { s_isel0 = isel; s_at0 = at; wA0 = wd; }
+                    if (item == w + NW) { s_isel1 = isel; s_at1 = at; wA1 = wd; }
                     ++item;
                 }
             }
@@ -401,44 +403,49 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
             scl_l[2] = 1.f / fmaxf((float)nA1, 1e-6f);
         }
     }
-    bf16x8 afr[8];
-    {
-        // A padding row of the tile is fed as a COPY of the tile's lowest valid row: its products repeat that row's
-        // exactly, so no column maximum changes and no row of the tile has to be masked out of the column side; a
-        // column winner that is such a copy is mapped back to the row it copies where the columns are finished.
+    const bool has0 = wA0 != 0u, has1 = wA1 != 0u;
+    const int P = has1 ? 2 : has0 ? 1 : 0;   // products of this wave per B tile
+    if (!has1) { s_isel1 = s_isel0; s_at1 = s_at0; wA1 = wA0; }   // one tile: both register sets serve it, on alternate B tiles
+    bf16x8 afr0[8], afr1[8];
+    // A padding row of the tile is fed as a COPY of the tile's lowest valid row: its products repeat that row's
+    // exactly, so no column maximum changes and no row of the tile has to be masked out of the column side; a
+    // column winner that is such a copy is mapped back to the row it copies where the columns are finished.
+    auto load_a = [&](bf16x8 (&afr)[8], int isel, int at, uint32_t wA) {
         const int arow = ((wA >> c) & 1u) ? c : __builtin_ctz(wA | 0x80000000u);
-        const int ig = max(ISEQ(slot_isel), 0);
+        const int ig = max(ISEQ(isel), 0);
         const size_t row0 = p.segA == 1 ? (size_t)ig * p.rowsA : (size_t)(ig / p.segA) * p.rowsA + (size_t)(ig % p.segA) * 256;
-        const uint16_t* src = p.hnA + (row0 + slot_at * 32 + arow) * FD + 8 * h;
+        const uint16_t* src = p.hnA + (row0 + at * 32 + arow) * FD + 8 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) afr[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
-    }
+    };
+    load_a(afr0, s_isel0, s_at0, wA0);
+    load_a(afr1, s_isel1, s_at1, wA1);
     // retire the A-fragment loads here (an opaque use), before any LDS-DMA is in flight
 #pragma unroll
-    for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(afr[s]));
+    for (int s = 0; s < 8; ++s) { asm volatile("" : "+v"(afr0[s])); asm volatile("" : "+v"(afr1[s])); }
 
     TL(2);
     const int T = __builtin_amdgcn_readfirstlane(cnt_l[0]);
     const int nE = T / SE;
 
-    // LDS-DMA.  Piece s = w % 8 of a tile is its k-step s: lane l (half l / 32, token l % 32)
-    // fetches bytes [32 s + 16 half, +16) of the token's 256-byte row and lands at chunk
-    // 64 s + l of the tile image.  Wave w serves the tiles w / 8, w / 8 + 2, ... of every epoch.
-    // Issued through inline asm: hipcc orders every later LDS read behind a DMA it knows of
-    // (vmcnt(0)), which would serialise the ring; this way the copies are counted by hand (SE / 2
-    // per epoch and wave, retired by the vmcnt waits in front of each epoch barrier).
-    const int piece = w & 7, dq = w >> 3;
+    // LDS-DMA.  Piece s of a tile is its k-step s: lane l (half l / 32, token l % 32) fetches bytes
+    // [32 s + 16 half, +16) of the token's 256-byte row and lands at chunk 64 s + l of the tile image.
+    // Wave w fetches piece w of every tile of an epoch.  Issued through inline asm: hipcc orders every
+    // later LDS read behind a DMA it knows of (vmcnt(0)), which would serialise the ring; this way the
+    // copies are counted by hand (SE per epoch and wave, retired by the vmcnt waits in front of each
+    // epoch barrier).
+    static_assert(NW == 8, "one wave per k-step piece of a tile");
+    const int piece = w;
     const unsigned char* hnB_bytes = reinterpret_cast<const unsigned char*>(p.hnB);
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + C::S_RING) + (uint32_t)piece * 1024u;
     // the lane's part of the source address: token ln % 32, k-step `piece`, half ln / 32
     const uint32_t dsrc_off = (uint32_t)(c * (FD * 2) + 32 * piece + 16 * h);
-    // g[k]: index of the tile (among all 32-token tiles of hnB) that wave-local DMA k of the epoch fetches
-    auto issue_epoch = [&](int E, const uint32_t (&g)[SE / 2]) {
+    // g[k]: index (among all 32-token tiles of hnB) of tile k of the epoch
+    auto issue_epoch = [&](int E, const uint32_t (&g)[SE]) {
 #pragma unroll
-        for (int k = 0; k < SE / 2; ++k) {   // SE * 8 pieces per epoch over 16 waves
-            const int tq = dq + 2 * k;
+        for (int k = 0; k < SE; ++k) {
             const unsigned char* src = hnB_bytes + (size_t)g[k] * (32 * FD * 2);   // scalar
-            const uint32_t dst = ring_lds + (uint32_t)((E % SNE) * SE + tq) * TILE_BYTES;
+            const uint32_t dst = ring_lds + (uint32_t)((E % SNE) * SE + k) * TILE_BYTES;
             uint32_t keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(dsrc_off), "s"(src), "s"(dst) : "memory");
@@ -447,24 +454,17 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     // The records of an epoch's tiles, read by eight lanes at once (lanes 0-3: the tiles of epoch E0, lanes 4-7:
     // those of epoch E1) and handed out as scalars by v_readlane.
     auto read_records = [&](int E0, int E1) { return meta[((lane & 4) ? E1 : E0) * SE + (lane & 3)]; };
-    auto dma_tiles = [&](const uint4& rec, int base_lane, uint32_t (&g)[SE / 2]) {
+    auto dma_tiles = [&](const uint4& rec, int base_lane, uint32_t (&g)[SE]) {
 #pragma unroll
-        for (int k = 0; k < SE / 2; ++k) g[k] = (uint32_t)__builtin_amdgcn_readlane((int)rec.y, base_lane + dq + 2 * k);
+        for (int k = 0; k < SE; ++k) g[k] = (uint32_t)__builtin_amdgcn_readlane((int)rec.y, base_lane + k);
     };
-
-    uint16_t* const arg_base = p.argA ? p.argA + ((size_t)max(ISEQ(slot_isel), 0) * p.ldc + p.col0 + j_begin) * p.TAp : nullptr;
-    float* const rowval_base = p.rowval ? p.rowval + ((size_t)max(ISEQ(slot_isel), 0) * p.ldc + p.col0 + j_begin) * p.TAp : nullptr;
-    int KM[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) KM[r] = NEG_KEY;
-    bool fresh = true;   // wave-uniform: no product of the current B sequence has been folded into KM yet
 
     // prologue: epochs 0 .. SNE-2 in flight, epoch 0 landed
     static_assert(SE == 4, "the tile records of an epoch are read by four lanes");
     for (int E = 0; E < SNE - 1; ++E)
         if (E < nE) {
             const uint4 rec = read_records(E, E);
-            uint32_t g[SE / 2];
+            uint32_t g[SE];
             dma_tiles(rec, 0, g);
             issue_epoch(E, g);
         }
@@ -473,16 +473,16 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     TL(3);
 
     // Emits the two scores of every sequence whose last tile lies in epoch E (all of its parts
-    // are complete one barrier after that epoch's own).  One wave does it — the last one when it
-    // holds no A tile, else the first (which the SIMD serves first) — with the LDS reads spread
+    // are complete two barriers after that epoch's own).  One wave does it — the last one when it
+    // holds at most one A tile, else one that finishes no columns — with the LDS reads spread
     // over its lanes: lane = (A sequence, tile of the epoch, A tile); lanes 0 and 32 then walk the
     // epoch's tiles in order and keep the running column sum of the sequence being streamed.
     static_assert(SE <= 4, "emit_epoch spreads at most four tiles of an epoch over the lanes");
     float runB = 0.f;
-    const int emit_w = n_items < NW ? NW - 1 : 0;
+    const int emit_w = n_items < 2 * NW ? NW - 1 : NW - SE - 1;
     auto emit_epoch = [&](int E) {
         if (w != emit_w) return;
-        const int par = E % 3;
+        const int par = E & 3;
         const int e_isel = lane >> 5, e_q = min((lane >> 3) & 3, SE - 1), e_at = lane & 7;
         float rs = mwa_l[e_isel * 8 + e_at] ? rowp[(par * SE + e_q) * 16 + e_isel * 8 + e_at] : 0.f;
         rs += __shfl_xor(rs, 1);
@@ -510,210 +510,265 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         }
     };
 
-#ifdef STREAM_STAMPS
-    unsigned seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long last_ = __builtin_readcyclecounter();
-#endif
+    // ---- rows of a finished B sequence for one A tile: transpose the running keys through the wave's
+    // LDS pad, lane (row, half) scans 16 of them ----
+    auto row_epilogue = [&](const int (&KM)[16], int isel, int at, uint32_t wA, int rowp_slot, uint32_t mz) {
+        int* tr = reinterpret_cast<int*>(smem + C::S_TR) + w * 32 * 36;
+        {
+            // an LDS-space pointer (32 bits): passed through an empty asm so that its arithmetic belongs to this
+            // branch and not to every product — as a generic pointer the sixteen writes became flat stores
+            typedef __attribute__((address_space(3))) int lds_int;
+            lds_int* trw = (lds_int*)(tr + 4 * h * 36 + c);
+            asm volatile("" : "+v"(trw));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) trw[((r & 3) + 8 * (r >> 2)) * 36] = KM[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        int k16[16];
+        {
+            const int4* rp = reinterpret_cast<const int4*>(tr + c * 36 + h * 16);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int4 v = rp[q4];
+                k16[4 * q4] = v.x; k16[4 * q4 + 1] = v.y; k16[4 * q4 + 2] = v.z; k16[4 * q4 + 3] = v.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // All sixteen keys of a row carry the same register tag in their low four bits: it is
+        // replaced by 15 - column, so that the maximum brings its (lowest) column along.  (A row that
+        // met no valid column holds negative keys throughout.)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) k16[k] = and_or_i(k16[k], ~15, 15 - k);
+        const int a0 = max3_i(k16[0], k16[1], k16[2]), a1 = max3_i(k16[3], k16[4], k16[5]), a2 = max3_i(k16[6], k16[7], k16[8]);
+        const int a3 = max3_i(k16[9], k16[10], k16[11]), a4 = max3_i(k16[12], k16[13], k16[14]);
+        int m = max(max3_i(a0, a1, a2), max3_i(a3, a4, k16[15]));
+        int cc;
+        {
+            // the other half's best; on equal keys the lower half (the lower columns) wins
+            const int om = xor32_i(m, lane);
+            const bool take = om + h > m;
+            m = take ? om : m;
+            cc = 15 - (m & 15) + 16 * (take ? 1 - h : h);
+        }
+        // every lane of both halves now holds row `c` of the tile: key m, winning lane cc
+        const bool valid = (wA >> c) & 1u;
+        const bool none = m < 0;
+        const float val = none ? -FLT_MAX : key_value(m);
+        const float rs = half32_sum(valid ? val : 0.f, lane);
+        if (lane == 0) rowp[rowp_slot * 16 + isel * 8 + at] = rs;
+        const size_t obase = ((size_t)max(ISEQ(isel), 0) * p.ldc + p.col0 + j_begin) * p.TAp;
+        const uint32_t o = (uint32_t)((int)(mz & 0xff) * p.TAp + at * 32 + c);
+        if (h == 0 && p.argA) (p.argA + obase)[o] = (none || !valid) ? (uint16_t)0 : (uint16_t)(((m >> 4) & 7) * 32 + cc);
+        if (h == 0 && p.rowval) (p.rowval + obase)[o] = val;
+    };
+
+    // A wave's work is a sequence of PRODUCTS (one of its A tiles against a B tile of the stream): with two A
+    // tiles, both against every tile; with one, that tile against the stream's tiles in turn.  Products alternate
+    // between two register sets (accumulator, A fragments, running row maxima): step A runs the matrix chain
+    // of a product into the first set BETWEEN the key instructions of the product before it, which sits in the
+    // second set; step B the other way round.  The source order is pinned by scheduling barriers and every
+    // instruction between them is volatile asm: the vector work of a product would otherwise sit behind its own
+    // chain on the wave's critical path, and the waves of a SIMD fall into step (all in the matrix phase, then
+    // all in the vector phase).  A product whose keys are still to be made is PENDING: it stays so across the
+    // epoch barrier.  Every record of the stream is multiplied, also an empty one (its image is a tile of finite
+    // numbers and none of its columns is valid: see cinit).
+    int tag[16];   // scalar: B tile << 4 | accumulator register, of the product whose keys are being made
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tag[r] = 0;
+#define SET_TAGS(bt4)                                                                                              \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile("s_or_b32 %0, %1, %2" : "=s"(tag[r]) : "s"(bt4), "n"(r) : "scc")
+#define KEYS_STEP(ACC, KM, CB, s)                                                                                  \
+    do {                                                                                                           \
+        int ka_, kb_;                                                                                              \
+        asm volatile("v_lshl_or_b32 %0, %1, 7, %2" : "=v"(ka_) : "v"(ACC[2 * (s)]), "s"(tag[2 * (s)]));              \
+        asm volatile("v_lshl_or_b32 %0, %1, 7, %2" : "=v"(kb_) : "v"(ACC[2 * (s) + 1]), "s"(tag[2 * (s) + 1]));      \
+        asm volatile("v_max_i32 %0, %0, %1" : "+v"(KM[2 * (s)]) : "v"(ka_));                                        \
+        asm volatile("v_max_i32 %0, %0, %1" : "+v"(KM[2 * (s) + 1]) : "v"(kb_));                                    \
+        asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(CB) : "v"(ka_), "v"(kb_));                                  \
+    } while (0)
+#define CHAIN_STEP(ACC, AFR, s) \
+    ACC = (s) == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(AFR[0], bfr[0], cinit, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(AFR[s], bfr[s], ACC, 0, 0, 0)
+    // chain of the new product (ACC_C, AFR) around the keys of the pending one (ACC_K into KM_K); the fragments
+    // of the next step's B tile replace the current ones behind their last use
+#define STEP(ACC_C, AFR, ACC_K, KM_K, CB)                       \
+    do {                                                        \
+        __builtin_amdgcn_sched_barrier(0);                      \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s) {         \
+            CHAIN_STEP(ACC_C, AFR, s);                          \
+            __builtin_amdgcn_sched_barrier(0);                  \
+            bfr[s] = nxt[64 * s];                               \
+            KEYS_STEP(ACC_K, KM_K, CB, s);                      \
+            __builtin_amdgcn_sched_barrier(0);                  \
+        }                                                       \
+    } while (0)
+
+    int KM0[16], KM1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) KM0[r] = KM1[r] = NEG_KEY;
+    // The accumulators start from 4.0 on valid columns of the B tile and from 2^31 on the others: there the sum
+    // stays 2^31 exactly (|a.b| <= 1 is far below its ulp), whose key is 0x80000000 | tag, below every key of a
+    // valid column and below the start value of the running maxima.  Sixteen registers, rewritten only when the
+    // column mask changes.
+    const float no_column = 2147483648.f;
+    f32x16 cinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = 4.f;
+    uint32_t cstate = 0xffffffffu;
+    auto set_columns = [&](uint32_t wB) {
+        if (wB != cstate) {
+            const float cv = ((wB >> c) & 1u) ? 4.f : no_column;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("v_mov_b32 %0, %1" : "+v"(cinit[r]) : "v"(cv));   // (keeps it a branch)
+            cstate = wB;
+        }
+    };
+    f32x16 acc0, acc1;   // the first pending product is a dummy without valid columns
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = no_column; acc1[r] = no_column; }
+    bf16x8 bfr[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bfr[s] = afr0[s];
+    typedef const __attribute__((address_space(3))) bf16x8* lds_frag_ptr;
+    const long long lo0 = (long long)((s_at0 << 1) | h), lo1 = (long long)((s_at1 << 1) | h);
+
+    // the pending product: its B tile << 4, its column-key slot, its row-sum slot, its record, whether it ends a sequence
+    int pd_bt4 = 0, pd_col = 0, pd_row = 0;
+    uint32_t pd_mz = 0u;
+    // the rows of the sequence that the pending product ended, after its keys went into Kp (with one A tile the
+    // two register sets hold parts of the same rows)
+    auto finish_rows = [&](int (&Kp)[16], int (&Ko)[16], int isel, int at, uint32_t wA) {
+        int kx[16];
+        const int neg = NEG_KEY;   // the running maxima start over, in place (a plain second assignment costs register copies after every product)
+        if (P == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kx[r] = max(Kp[r], Ko[r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("v_mov_b32 %0, %1" : "+v"(Ko[r]) : "v"(neg));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kx[r] = Kp[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("v_mov_b32 %0, %1" : "+v"(Kp[r]) : "v"(neg));
+        row_epilogue(kx, isel, at, wA, pd_row, pd_mz);
+    };
+    auto ring_slot = [&](int slot) { return (lds_frag_ptr)(lds_ptr_t)(smem + C::S_RING + slot * TILE_BYTES + lane * 16); };
+
+    // ---- columns of epoch E's tiles (complete one barrier after the epoch's own: the last product's keys are made
+    // in the next epoch), by the SE waves that hold the fewest A tiles ----
+    auto column_duty = [&](int E) {
+        const int duty0 = NW - SE;
+        if (w < duty0 || w >= duty0 + SE) return;
+        const int q = w - duty0, isel = h;
+        const uint4 m4 = meta[E * SE + q];
+        long long* cp = &col64[(((E % 3) * SE + q) * 2 + isel) * 32 + c];
+        const long long key = *cp;
+        *cp = NEG_KEY64;
+        if (m4.w & FLAG_NULL) return;
+        const bool valid = ((m4.x >> c) & 1u) && (ISEQ(isel) >= 0);
+        float cv = 0.f;
+        if (valid) {
+            const int hi = (int)(key >> 32), lo = (int)(key & 0xffffffffLL);
+            int barg = 0;
+            if (hi < 0) {
+                cv = -FLT_MAX;
+            } else {
+                cv = key_value(hi);
+                const int at = lo >> 1, rr = acc_row(hi & 15, lo & 1);
+                const uint32_t wd = mwa_l[isel * 8 + at];
+                barg = at * 32 + (((wd >> rr) & 1u) ? rr : __builtin_ctz(wd | 0x80000000u));   // a copy -> the row it copies
+            }
+            if (p.argB)
+                p.argB[((size_t)ISEQ(isel) * p.ldc + p.col0 + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = (uint16_t)barg;
+            if (p.colval)
+                p.colval[((size_t)ISEQ(isel) * p.ldc + p.col0 + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = cv;
+        }
+        const float cs = half32_sum(cv, lane);
+        if (c == 0) colpart[((E & 3) * SE + q) * 2 + isel] = cs;
+    };
+
     for (int e = 0; e < nE; ++e) {
         const bool ahead = e + SNE - 1 < nE;
         // this epoch's tile records and the tiles of the epoch to fetch, as scalars
         const uint4 rec = read_records(e, ahead ? e + SNE - 1 : e);
         if (ahead) {
-            uint32_t g[SE / 2];
+            uint32_t g[SE];
             dma_tiles(rec, 4, g);
             issue_epoch(e + SNE - 1, g);
         }
-        STAMP(0);
         const int ring0 = (e % SNE) * SE;
-        const int par2 = e & 1, par3 = e % 3;
-        uint32_t t_wB[SE], t_mz[SE];   // column mask; B sequence | B tile << 8 | flags << 16
+        const int col_e = (e % 3) * SE, row_e = (e & 3) * SE;
+        const int nsteps = P * SE;   // products of this wave in the epoch
+        if (P) {
+            lds_frag_ptr cur = ring_slot(ring0);
 #pragma unroll
-        for (int q = 0; q < SE; ++q) {
-            t_wB[q] = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, q);
-            t_mz[q] = (uint32_t)__builtin_amdgcn_readlane((int)rec.z, q);
+            for (int s = 0; s < 8; ++s) bfr[s] = cur[64 * s];
         }
-        STAMP(1);
-
-#pragma unroll
-        for (int q = 0; q < SE; ++q) {
-            const uint32_t wB = t_wB[q], mz = t_mz[q], fl = mz >> 16;
-            const int bt = (mz >> 8) & 7;
-            // Issue priority by progress: of the four waves on a SIMD the one that is furthest behind
-            // in the epoch goes first.  Left alone the SIMD serves its oldest wave first, the waves
-            // finish the epoch one after the other and the last one runs its products alone, at a
-            // third of the issue rate, while the others wait at the barrier (5 % of the kernel).
-            if (q == 0) __builtin_amdgcn_s_setprio(3);
-            else if (q == 1) __builtin_amdgcn_s_setprio(2);
-            else if (q == 2) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-            if (wB != 0 && wA != 0) {
-                bf16x8 bfr[8];
-                {
-                    const unsigned char* base = smem + C::S_RING + (ring0 + q) * TILE_BYTES + lane * 16;
-#pragma unroll
-#ifdef ABL_NOFRAG   // timing experiments only: no fragment reads (wrong results)
-                    for (int s = 0; s < 8; ++s) { bfr[s] = afr[(s + 1) & 7]; asm volatile("" : "+v"(bfr[s])); }
-                    asm volatile("" ::"v"(base));
-#elif defined(ABL_HALFFRAG)   // timing experiments only: half the fragment reads
-                    for (int s = 0; s < 4; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(base + 1024 * s);
-                    for (int s = 4; s < 8; ++s) { bfr[s] = bfr[s - 4]; asm volatile("" : "+v"(bfr[s])); }
-#else
-                    for (int s = 0; s < 8; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(base + 1024 * s);
-#endif
-                }
-                const f32x16 four = {4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f, 4.f};
-                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], four, 0, 0, 0);
-#pragma unroll
-                for (int s = 1; s < ABL_MFMA_STEPS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], bfr[s], acc, 0, 0, 0);
-#ifndef ABL_NOHOIST
-                // four fragment reads in flight ahead of the matrix instructions (16 registers):
-                // one LDS latency per tile instead of four, 2 % faster
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#endif
-#ifdef STREAM_STAMPS
-                asm volatile("s_nop 0" ::"v"(acc));   // the matrix results have arrived
-                STAMP(2);
-#endif
-#ifdef ABL_NOEPI
-                asm volatile("" ::"v"(acc));
-#else
-                int key[16];
-                make_keys(acc, key, bt << 4);
-                if (wB != 0xffffffffu) mask_keys(key, ((unsigned long long)wB << 32) | wB);
-                if (fresh) row_fold<true>(key, KM);
-                else row_fold<false>(key, KM);
-                fresh = false;
-                const int cb = col_max(key);
-#ifndef ABL_NOATOMIC
-                atomicMax(&col64[((par2 * SE + q) * 2 + slot_isel) * 32 + c], ((long long)cb << 32) | (long long)((slot_at << 1) | h));
-#else
-                asm volatile("" ::"v"(cb));
-#endif
-#endif
-                STAMP(3);
+#pragma unroll 1
+        for (int n = 0; n < nsteps; n += 2) {
+            // two A tiles: both steps take tile n / 2; one: tiles n and n + 1
+            const int qA = P == 2 ? n >> 1 : n, qB = P == 2 ? n >> 1 : n + 1;
+            {   // ---- step A: tile qA against the first register set; keys of the pending product (second set) ----
+                const uint32_t wB = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, qA);
+                const uint32_t mz = (uint32_t)__builtin_amdgcn_readlane((int)rec.z, qA);   // B sequence | B tile << 8 | flags << 16
+                set_columns(wB);
+                SET_TAGS(pd_bt4);
+                lds_frag_ptr nxt = ring_slot(ring0 + qB);
+                int cb = NEG_KEY;
+                STEP(acc0, afr0, acc1, KM1, cb);
+                atomicMax(&col64[pd_col + c], ((long long)cb << 32) | lo1);
+                if ((pd_mz >> 16) & FLAG_LAST) finish_rows(KM1, KM0, s_isel1, s_at1, wA1);
+                pd_bt4 = (int)((mz >> 8) & 7u) << 4;
+                pd_col = ((col_e + qA) * 2 + s_isel0) * 32;
+                pd_row = row_e + qA;
+                pd_mz = mz;
             }
-#ifndef ABL_NOROWEPI   // timing experiments only: no row epilogue (wrong results)
-            if ((fl & FLAG_LAST) && wA != 0) {
-                // ---- rows of the finished B sequence: transpose the keys, lane (row, half) scans 16 ----
-                int* tr = reinterpret_cast<int*>(smem + C::S_TR) + w * 32 * 36;
-                {
-                    // an LDS-space pointer (32 bits): passed through an empty asm so that its arithmetic belongs to this
-                    // branch and not to every product — as a generic pointer the sixteen writes became flat stores
-                    typedef __attribute__((address_space(3))) int lds_int;
-                    lds_int* trw = (lds_int*)(tr + 4 * h * 36 + c);
-                    asm volatile("" : "+v"(trw));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) trw[((r & 3) + 8 * (r >> 2)) * 36] = KM[r];
-                }
-                const bool empty_b = fresh;   // an empty B sequence: nothing was folded in, KM is stale
-                fresh = true;
-                __builtin_amdgcn_wave_barrier();
-                int k16[16];
-                {
-                    const int4* rp = reinterpret_cast<const int4*>(tr + c * 36 + h * 16);
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const int4 v = rp[q4];
-                        k16[4 * q4] = v.x; k16[4 * q4 + 1] = v.y; k16[4 * q4 + 2] = v.z; k16[4 * q4 + 3] = v.w;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                // All sixteen keys of a row carry the same register tag in their low four bits: it is
-                // replaced by 15 - column, so that the maximum brings its (lowest) column along.
-#pragma unroll
-                for (int k = 0; k < 16; ++k) k16[k] = and_or_i(k16[k], ~15, 15 - k);
-                const int a0 = max3_i(k16[0], k16[1], k16[2]), a1 = max3_i(k16[3], k16[4], k16[5]), a2 = max3_i(k16[6], k16[7], k16[8]);
-                const int a3 = max3_i(k16[9], k16[10], k16[11]), a4 = max3_i(k16[12], k16[13], k16[14]);
-                int m = max(max3_i(a0, a1, a2), max3_i(a3, a4, k16[15]));
-                m = empty_b ? NEG_KEY : m;
-                int cc;
-                {
-                    // the other half's best; on equal keys the lower half (the lower columns) wins
-                    const int om = xor32_i(m, lane);
-                    const bool take = om + h > m;
-                    m = take ? om : m;
-                    cc = 15 - (m & 15) + 16 * (take ? 1 - h : h);
-                }
-                // every lane of both halves now holds row `c` of the tile: key m, winning lane cc
-                const bool valid = (wA >> c) & 1u;
-                const bool none = m < 0;
-                const float val = none ? -FLT_MAX : key_value(m);
-                const float rs = half32_sum(valid ? val : 0.f, lane);
-                if (lane == 0) rowp[(par3 * SE + q) * 16 + slot_isel * 8 + slot_at] = rs;
-                if (h == 0 && p.argA)   // scalar base of this wave's A sequence and B chunk, 32-bit lane offset
-                    arg_base[(uint32_t)((int)(mz & 0xff) * p.TAp + slot_at * 32 + c)] =
-                        (none || !valid) ? (uint16_t)0 : (uint16_t)(((m >> 4) & 7) * 32 + cc);
-                if (h == 0 && rowval_base) rowval_base[(uint32_t)((int)(mz & 0xff) * p.TAp + slot_at * 32 + c)] = val;
-                STAMP(4);
+            {   // ---- step B: tile qB against the second register set; keys of the pending product (first set) ----
+                const uint32_t wB = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, qB);
+                const uint32_t mz = (uint32_t)__builtin_amdgcn_readlane((int)rec.z, qB);
+                set_columns(wB);
+                SET_TAGS(pd_bt4);
+                // the next step's tile; behind the epoch's last step the current one again (the next epoch's may not have landed)
+                const int qN = P == 2 ? qB + 1 : qB + 1;
+                lds_frag_ptr nxt = ring_slot(ring0 + min(qN, SE - 1));
+                int cb = NEG_KEY;
+                STEP(acc1, afr1, acc0, KM0, cb);
+                atomicMax(&col64[pd_col + c], ((long long)cb << 32) | lo0);
+                if ((pd_mz >> 16) & FLAG_LAST) finish_rows(KM0, KM1, s_isel0, s_at0, wA0);
+                pd_bt4 = (int)((mz >> 8) & 7u) << 4;
+                pd_col = ((col_e + qB) * 2 + s_isel1) * 32;
+                pd_row = row_e + qB;
+                pd_mz = mz;
             }
-#endif
         }
 
         // epoch e+1 has landed once all but the DMAs of the later epochs are retired
-        if (ahead) wait_vmcnt<(SNE - 2) * (SE / 2)>();
+        if (ahead) wait_vmcnt<(SNE - 2) * SE>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS atomics and writes are done
-        STAMP(5);
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(3);   // duty waves start the next epoch behind the others
-        STAMP(6);
-
-        // ---- columns of this epoch's tiles, by SE waves: waves without an A tile when there are
-        // enough of them, else the oldest one of every SIMD (served first, they have the most slack
-        // before the next barrier: 1 % faster than rotating the duty) ------------------------------
-        const int duty0 = (NW - n_items >= SE) ? NW - SE : 0;
-#ifndef ABL_NODUTY   // timing experiments only: columns never finished (wrong results)
-        if (w >= duty0 && w < duty0 + SE) {
-            const int q = w - duty0, isel = h;
-            const uint4 m4 = meta[e * SE + q];
-            long long* cp = &col64[((par2 * SE + q) * 2 + isel) * 32 + c];
-            const long long key = *cp;
-            *cp = NEG_KEY64;
-            if (!(m4.w & FLAG_NULL)) {
-                const bool valid = ((m4.x >> c) & 1u) && (ISEQ(isel) >= 0);
-                float cv = 0.f;
-                if (valid) {
-                    const int hi = (int)(key >> 32), lo = (int)(key & 0xffffffffLL);
-                    int barg = 0;
-                    if (hi < 0) {
-                        cv = -FLT_MAX;
-                    } else {
-                        cv = key_value(hi);
-                        const int at = lo >> 1, rr = acc_row(hi & 15, lo & 1);
-                        const uint32_t wd = mwa_l[isel * 8 + at];
-                        barg = at * 32 + (((wd >> rr) & 1u) ? rr : __builtin_ctz(wd | 0x80000000u));   // a copy -> the row it copies
-                    }
-                    if (p.argB)
-                        p.argB[((size_t)ISEQ(isel) * p.ldc + p.col0 + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = (uint16_t)barg;
-                    if (p.colval)
-                        p.colval[((size_t)ISEQ(isel) * p.ldc + p.col0 + j_begin + (int)(m4.z & 0xff)) * p.TBp + ((m4.z >> 8) & 7) * 32 + c] = cv;
-                }
-                const float cs = half32_sum(cv, lane);
-                if (c == 0) colpart[(par3 * SE + q) * 2 + isel] = cs;
-            }
-        }
-#endif
-        if (e > 0) emit_epoch(e - 1);
-        STAMP(7);
+        if (e > 0) column_duty(e - 1);
+        if (e > 1) emit_epoch(e - 2);
     }
-#ifdef STREAM_STAMPS
-    if (lane == 0 && p.dbg)
-        for (int k = 0; k < 8; ++k) p.dbg[((size_t)blockIdx.x * NW + w) * 8 + k] = seg_[k];
-#endif
 #ifdef STREAM_TIMELINE
     if (p.tl && lane == 0) p.tl[(size_t)blockIdx.x * 32 + 4 + w] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (nE > 0) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-        emit_epoch(nE - 1);
+    // the last product's keys
+    if (P) {
+        SET_TAGS(pd_bt4);
+        int cb = NEG_KEY;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) KEYS_STEP(acc1, KM1, cb, s);
+        atomicMax(&col64[pd_col + c], ((long long)cb << 32) | lo1);
+        if ((pd_mz >> 16) & FLAG_LAST) finish_rows(KM1, KM0, s_isel1, s_at1, wA1);
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    column_duty(nE - 1);
+    if (nE > 1) emit_epoch(nE - 2);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    emit_epoch(nE - 1);
 #ifdef STREAM_TIMELINE
     if (p.tl && lane == 0 && w == 0) {
         p.tl[(size_t)blockIdx.x * 32 + 20] = __builtin_amdgcn_s_memrealtime();

@@ -194,6 +194,25 @@ def rank_shape_records(K, device):
     return out
 
 
+def library_gemm_tflops(device, n=8192, reps=20):
+    """Rate of the library's plain bf16 GEMM (torch.matmul -> hipBLASLt) on random operands, measured on this GPU:
+    the matrix cores' sustained rate depends on the operand data (with all-zero operands the same GEMM runs a third
+    faster), so the nominal peak is not reachable on real data and this is the practical ceiling beside it."""
+    g = torch.Generator(device="cpu").manual_seed(7)
+    a = torch.randn(n, n, generator=g).to(device=device, dtype=torch.bfloat16)
+    b = torch.randn(n, n, generator=g).to(device=device, dtype=torch.bfloat16)
+    for _ in range(3):
+        a @ b
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        a @ b
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n ** 3 / (e0.elapsed_time(e1) / reps * 1e-3) / 1e12
+
+
 def long_chain_record(K, device):
     """The FILIP scores of a batch of long chains (the reference keeps chains of up to 2,000 residues,
     modules/data_utils_2protein.py:88,133; its FILIP entry script runs batches of 10): 16 x 16 sequences of 1,000
@@ -438,6 +457,13 @@ def main():
                     "sim_kernel_ms": full_ms, "sim_kernel_TFLOPs": ff / (full_ms * 1e-3) / 1e12,
                     "sim_kernel_mfma_frac": ff / (full_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                 }
+        if not multi and do_filip and not args.no_rank_shapes:
+            # context for `roofline.frac` (which stays against the nominal peak): what the library's GEMM sustains here
+            lib = library_gemm_tflops(device)
+            roof["library_gemm"] = {"TFLOPs": lib, "what": "torch.matmul bf16 8192^3, random operands, same GPU, same run",
+                                    "achieved_over_it": roof["achieved"] / lib}
+            if "filip_full_length_scores" in workloads:
+                workloads["filip_full_length_scores"]["over_library_gemm"] = workloads["filip_full_length_scores"]["sim_kernel_TFLOPs"] / lib
         if not multi and not args.no_rank_shapes and args.workload == "both":
             workloads.update(rank_shape_records(K, device))
             workloads.update(head_record(K, device))

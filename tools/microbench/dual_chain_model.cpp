@@ -58,6 +58,16 @@ __global__ __launch_bounds__(NW * 64) void k4(const bf16x8* __restrict__ in, int
                   for (int s = 0; s < 8; ++s) { x1 = MFMA(a1[s], b[s], s == 0 ? four : x1); SB(); b[s] = next[64 * s]; KEYS_STEP(x0, km0, cb, s); SB(); }
                   atomicMax(&col[(((it + u) & 7) * 2) * 32 + (lane & 31)], ((long long)cb << 32) | lane); }
             }
+        } else if (V == 7) {
+            // matrix chains only, two A tiles per wave: every fragment set feeds two chains
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                lds_frag* next = (lds_frag*)(smem + ((it + u + 1) & 7) * 8192 + lane * 16);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { x0 = MFMA(a0[s], b[s], s == 0 ? four : x0); x1 = MFMA(a1[s], b[s], s == 0 ? four : x1); b[s] = next[64 * s]; }
+                asm volatile("" : "+v"(x0), "+v"(x1));
+                km0[u] ^= __float_as_int(x0[u]) ^ __float_as_int(x1[u]);
+            }
         } else if (V == 5 || V == 6) {
             // matrix chains only (V5: operands stay in registers; V6: fragments re-read from LDS behind their use)
 #pragma unroll
@@ -134,7 +144,7 @@ static void run(const char* name, bf16x8* in, int* out) {
         (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
-    const double ns = best * 1e6 / iters / (NW / 4) / (V >= 3 ? 1 : 2);   // per product and SIMD
+    const double ns = best * 1e6 / iters / (NW / 4) / ((V >= 3 && V != 7) ? 1 : 2);   // per product and SIMD
     printf("%-64s %6.1f ns per product and SIMD  (%4.0f TFLOP/s)\n", name, ns, 1024.0 * 8 * 32768 / ns * 1e-3);
 }
 
@@ -153,6 +163,8 @@ int main() {
     run<8, 3, 1>("8 waves x 1 tile, chain of the next tile || keys", in, out);
     run<16, 5, 1>("16 waves, matrix chains only, registers, zero operands", in, out);
     run<16, 6, 1>("16 waves, matrix chains only, LDS fragments, zero operands", in, out);
+    run<8, 7, 1>("8 waves x 2 tiles, matrix chains only, zero operands", in, out);
+    run<16, 7, 1>("16 waves x 2 tiles, matrix chains only, zero operands", in, out);
     // the same with random operands (bf16 in [-0.125, 0.125]): matrix power and clocks depend on the data
     {
         unsigned short* h = new unsigned short[4096 * 8];
@@ -163,6 +175,9 @@ int main() {
         run<8, 1, 1>("8 waves, one chain at a time, RANDOM operands", in, out);
         run<16, 5, 1>("16 waves, matrix chains only, registers, RANDOM operands", in, out);
         run<16, 6, 1>("16 waves, matrix chains only, LDS fragments, RANDOM operands", in, out);
+        run<8, 7, 1>("8 waves x 2 tiles, matrix chains only, RANDOM operands", in, out);
+        run<12, 7, 1>("12 waves x 2 tiles, matrix chains only, RANDOM operands", in, out);
+        run<16, 7, 1>("16 waves x 2 tiles, matrix chains only, RANDOM operands", in, out);
     }
     return 0;
 }

@@ -142,4 +142,9 @@ def test_filip_rank_shape_256_by_2048(K):
     assert rel < 4e-3, rel   # twice what tools/measure_bwd_outliers.py measured at this shape (profiles/r3_bwd_outliers.txt: 1.8e-3, 2.0e-3)
     _, db = oracle(hA, hB[1500:1501], mA, mB[1500:1501], gA[:, 1500:1501], gB[:, 1500:1501])
     rel = ((dB[1500:1501] - db).norm() / db.norm()).item()
-    assert rel < 4e-3, rel
+    # One B sequence has 256 pairs only, so a single token routed differently from the oracle's f32 host einsum, or one
+    # operand that host and device round to different bf16 values, shows: 2.0e-3 and 7.1e-3 were seen for this very
+    # sequence on two boxes (the host's rounding depends on its thread count), 7.95e-3 for single B sequences at the
+    # benchmark shape (profiles/r3_bwd_outliers.txt).  Budget: twice the largest.  The exact check is the one above
+    # (every token equals the float64 sum of the rows its arg indices route to).
+    assert rel < 1.6e-2, rel

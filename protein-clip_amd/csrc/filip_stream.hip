@@ -37,7 +37,8 @@ extern "C" { unsigned long long* g_stream_dbg = nullptr; }
 #endif
 // Diagnostic build (-DSTREAM_TIMELINE): wall-clock stamps (100 MHz counter) of every workgroup's phases and the CU it
 // ran on, to g_stream_tl[block * 32 + k]: 0 entry, 1 pairing done, 2 set-up done, 3 first epoch landed, 4 + w end of
-// wave w's main loop, 20 end of the workgroup, 21 hardware id, 22 XCC id.
+// wave w's main loop, 20 end of the workgroup, 21 hardware id, 22 XCC id, 23 / 24 the shader-clock counter at entry and
+// end (with 0 and 20: the clock the workgroup's CU really ran at).
 #ifdef STREAM_TIMELINE
 extern "C" { unsigned long long* g_stream_tl = nullptr; }
 #define TL(k) do { if (p.tl && lane == 0 && w == 0) p.tl[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -234,6 +235,9 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
     const int nj = j_end - j_begin;
     const int ntA = p.TAp >> 5, ntB = p.TBp >> 5;
     TL(0);
+#ifdef STREAM_TIMELINE
+    if (p.tl && lane == 0 && w == 0) p.tl[(size_t)blockIdx.x * 32 + 23] = __builtin_readcyclecounter();
+#endif
 
     // ---- which two A sequences: pairs whose valid-tile counts sum to a multiple of four --------
     // Sixteen waves sit on four SIMDs, so a workgroup takes ceil(tiles / 4) tile rounds per B
@@ -719,6 +723,7 @@ __global__ __launch_bounds__(1024) void filip_sim_stream_kernel(FilipStreamArgs 
         p.tl[(size_t)blockIdx.x * 32 + 20] = __builtin_amdgcn_s_memrealtime();
         p.tl[(size_t)blockIdx.x * 32 + 21] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
         p.tl[(size_t)blockIdx.x * 32 + 22] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+        p.tl[(size_t)blockIdx.x * 32 + 24] = __builtin_readcyclecounter();
     }
 #endif
 }

@@ -11,6 +11,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #define SB() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ unsigned long long shader_cycles() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+__device__ __forceinline__ unsigned long long ticks_100mhz() { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
 #define SET_TAGS(bt4) _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile("s_or_b32 %0, %1, %2" : "=s"(tag[r]) : "s"(bt4), "n"(r) : "scc")
 #define KEYS_STEP(ACC, KM, CB, s)                                                                                  \
     do {                                                                                                           \
@@ -41,6 +43,7 @@ __global__ __launch_bounds__(NW * 64) void k4(const bf16x8* __restrict__ in, int
     { lds_frag* cur = (lds_frag*)(smem + lane * 16);
 #pragma unroll
       for (int s = 0; s < 8; ++s) b[s] = cur[64 * s]; }
+    const unsigned long long c0_ = shader_cycles(), r0_ = ticks_100mhz();
     for (int it = 0; it < iters; it += 2) {
         if (V == 1) {
 #pragma unroll
@@ -126,6 +129,11 @@ __global__ __launch_bounds__(NW * 64) void k4(const bf16x8* __restrict__ in, int
     for (int r = 0; r < 16; ++r) x ^= km0[r] ^ __float_as_int(x0[r]) ^ __float_as_int(x1[r]);
     if (V < 3) for (int r = 0; r < 16; ++r) x ^= km1[r] ^ __float_as_int(y0[r]) ^ __float_as_int(y1[r]);
     out[blockIdx.x * NW * 64 + tid] = x;
+    if (blockIdx.x == 0 && tid == 0) {   // shader-clock cycles and 100-MHz ticks of the loop: the clock the SIMDs really ran at
+        unsigned long long* cl = reinterpret_cast<unsigned long long*>(out + 256 * 1024 + 8);
+        cl[0] = shader_cycles() - c0_;
+        cl[1] = ticks_100mhz() - r0_;
+    }
 }
 
 template <int NW, int V, int RELOADS>
@@ -145,13 +153,16 @@ static void run(const char* name, bf16x8* in, int* out) {
         if (ms < best) best = ms;
     }
     const double ns = best * 1e6 / iters / (NW / 4) / ((V >= 3 && V != 7) ? 1 : 2);   // per product and SIMD
-    printf("%-64s %6.1f ns per product and SIMD  (%4.0f TFLOP/s)\n", name, ns, 1024.0 * 8 * 32768 / ns * 1e-3);
+    unsigned long long cl[2] = {0, 0};
+    (void)hipMemcpy(cl, out + 256 * 1024 + 8, sizeof(cl), hipMemcpyDeviceToHost);
+    const double mhz = cl[1] ? (double)cl[0] / ((double)cl[1] / 100.0) : 0.0;
+    printf("%-64s %6.1f ns per product and SIMD  (%4.0f TFLOP/s)  shader clock %4.0f MHz\n", name, ns, 1024.0 * 8 * 32768 / ns * 1e-3, mhz);
 }
 
 int main() {
     bf16x8* in; int* out;
     (void)hipMalloc(&in, 4096 * sizeof(bf16x8)); (void)hipMemset(in, 0, 4096 * sizeof(bf16x8));
-    (void)hipMalloc(&out, 256 * 1024 * 4);
+    (void)hipMalloc(&out, 256 * 1024 * 4 + 64);
     run<8, 1, 1>("8 waves, one chain at a time, fragments read once", in, out);
     run<8, 1, 2>("8 waves, one chain at a time, fragments read twice", in, out);
     run<8, 2, 1>("8 waves, two chains alternating || keys of the tile before", in, out);

@@ -95,3 +95,7 @@ print("duration histogram (25-us bins):", dict(sorted(hist.items())))
 if os.environ.get("TL_DUMP"):
     for key in sorted(cus)[:40]:
         print("xcc %d se/sh/cu %02x:" % key, "  ".join("b%d[%d..%d]" % (w["b"], w["start"], w["end"]) for w in cus[key]))
+mhz = [(int(r[24]) - int(r[23])) / ((int(r[20]) - int(r[0])) / 100.0) for r in v if int(r[20]) > int(r[0]) and int(r[24]) > int(r[23])]
+if mhz:
+    print("shader clock while the kernel runs (cycle counter over the 100-MHz counter, per workgroup): median %.0f MHz, min %.0f, max %.0f" % (
+        st.median(mhz), min(mhz), max(mhz)))

@@ -372,7 +372,10 @@ def main():
     total = bracket(lambda i: step(i), args.steps)
     step_allocs = allocs["n"]   # device allocations made by the timed steps
     if multi and step_allocs != 0:
-        raise SystemExit(f"the sharded steps allocated device memory {step_allocs} times inside the timed region (expected: none)")
+        msg = f"the sharded steps allocated device memory {step_allocs} times inside the timed region (expected: none)"
+        if rehearse:   # the rehearsal is the check; a real multi-GPU run reports the count in its JSON line and goes on
+            raise SystemExit(msg)
+        print("bench.py: " + msg, file=sys.stderr)
     sim_ms = statistics.mean(e0.elapsed_time(e1) for e0, e1 in events) if do_filip else None
     bwd_ms = statistics.mean(e0.elapsed_time(e1) for e0, e1 in bwd_events) if do_filip and filip_fused is not None else None
 

@@ -169,6 +169,8 @@ int main() {
     run<4, 1, 1>("4 waves (one per SIMD), one chain at a time", in, out);
     run<4, 2, 1>("4 waves (one per SIMD), two chains alternating", in, out);
     run<16, 4, 1>("16 waves x 1 tile, plain order", in, out);
+    run<12, 4, 1>("12 waves x 1 tile, plain order", in, out);
+    run<8, 4, 1>("8 waves x 1 tile, plain order", in, out);
     run<16, 3, 1>("16 waves x 1 tile, chain of the next tile || keys", in, out);
     run<12, 3, 1>("12 waves x 1 tile, chain of the next tile || keys", in, out);
     run<8, 3, 1>("8 waves x 1 tile, chain of the next tile || keys", in, out);
@@ -183,6 +185,9 @@ int main() {
         for (int i = 0; i < 4096 * 8; ++i) { x = x * 1664525u + 1013904223u; h[i] = (unsigned short)(((x >> 16) & 0x80ffu) | 0x3d00u); }
         (void)hipMemcpy(in, h, 4096 * sizeof(bf16x8), hipMemcpyHostToDevice);
         run<16, 4, 1>("16 waves x 1 tile, plain order, RANDOM operands", in, out);
+        run<12, 4, 1>("12 waves x 1 tile, plain order, RANDOM operands", in, out);
+        run<12, 3, 1>("12 waves x 1 tile, chain of the next tile || keys, RANDOM operands", in, out);
+        run<8, 4, 1>("8 waves x 1 tile, plain order, RANDOM operands", in, out);
         run<8, 1, 1>("8 waves, one chain at a time, RANDOM operands", in, out);
         run<16, 5, 1>("16 waves, matrix chains only, registers, RANDOM operands", in, out);
         run<16, 6, 1>("16 waves, matrix chains only, LDS fragments, RANDOM operands", in, out);

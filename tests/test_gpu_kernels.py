@@ -770,6 +770,39 @@ def test_filip_long_segments_agree_with_the_general_kernel(K):
     close(res[0][1], res[1][1].cpu(), 2e-6, 2e-6)
 
 
+def test_filip_long_segments_in_workspace_bounded_column_blocks(K):
+    """A long-sequence problem whose segment tables exceed the library's workspace budget (32 x 768 sequences of about
+    1,000 tokens: the launch runs in column blocks inside the one call) against the same problem scored in explicit
+    column blocks that each stay under the budget, and against a call without arg tables: identical results."""
+    from protein_clip_amd import _lib
+    gen = torch.Generator().manual_seed(5)
+    Br, Bc, TA, TB, d = 32, 768, 1000, 1024, 128
+    hA, hB = dev(torch.randn(Br, TA, d, generator=gen)), dev(torch.randn(Bc, TB, d, generator=gen))
+    lA, lB = torch.randint(300, TA + 1, (Br,), generator=gen), torch.randint(1, TB + 1, (Bc,), generator=gen)
+    lB[3] = 0
+    mA, mB = dev(O.right_padded_masks(lA, TA)), dev(O.right_padded_masks(lB, TB))
+    t = dev(torch.tensor([0.9]))
+    hnA, mwA = K.filip_prep(hA, mA, True, tsign=t)
+    hnB, mwB = K.filip_prep(hB, mB, True)
+    lib = _lib.load()
+    whole = lib.pclip_filip_sim_fwd_workspace_bytes(Br, TA, Bc, TB, 1)
+    assert whole < 6 * Br * Bc * (1024 + 1024)   # bounded: less than the tables of all columns at once
+    sA, sB, aA, aB = K.filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, want_arg=True, unit_norm=True)
+    out = (torch.empty_like(sA), torch.empty_like(sB), torch.empty_like(aA), torch.empty_like(aB))
+    for c0 in range(0, Bc, 96):
+        c1 = min(Bc, c0 + 96)
+        assert lib.pclip_filip_sim_fwd_workspace_bytes(Br, TA, c1 - c0, TB, 1) < whole
+        K.filip_sim_fwd(hnA, mwA, TA, hnB[c0:c1], mwB[c0:c1], TB, t, want_arg=True, unit_norm=True, out=out, col_offset=c0)
+    keep = dev(lB > 0)
+    assert torch.equal(sA[:, keep], out[0][:, keep]) and torch.equal(sB, out[1])
+    assert torch.isinf(sA[:, 3]).all() and (sB[:, 3] == 0).all()
+    vA = mA.bool()[:, None, :] & keep[None, :, None]
+    vB = mB.bool()[None, :, :].expand(Br, Bc, TB)
+    assert not ((aA[..., :TA] != out[2][..., :TA]) & vA).any() and not ((aB[..., :TB] != out[3][..., :TB]) & vB).any()
+    s2A, s2B, _, _ = K.filip_sim_fwd(hnA, mwA, TA, hnB, mwB, TB, t, want_arg=False, unit_norm=True)
+    assert torch.equal(sA[:, keep], s2A[:, keep]) and torch.equal(sB, s2B)
+
+
 @pytest.mark.parametrize("TA,TB,normalise", [(300, 270, True), (40, 333, True), (290, 64, False), (1000, 1000, True), (2000, 600, True)])
 def test_filip_sequences_beyond_one_lds_image(K, TA, TB, normalise):
     """Chains longer than 256 tokens (the reference keeps up to 2,000 residues,

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-WORLD = 2
+WORLD = int(os.environ.get("PCLIP_TEST_WORLD", "2"))   # 3 puts a rank in the middle (partner blocks before AND behind its own)
 
 
 def _inputs():
